@@ -1,0 +1,396 @@
+// BatchNorm (training + eval) for NHWC activations viewed as [M][C], with the
+// ReLU and residual-add of a ResNet block fused into the same passes
+// (reference trigger: torchvision's BatchNorm2d/ReLU inside
+// `model(images)`, /root/reference/2.distributed.py:213).
+//
+// Forward (train):  statistics are per-tile partial sums (written either by the
+// conv epilogue or by bn_stats_partial_kernel), reduced in fp64 by
+// bn_finalize_kernel, which also updates the running statistics and emits the
+// fused per-channel scale/shift; bn_apply_kernel then does
+//     out = relu(y * scale[c] + shift[c] + residual)
+// in one 16-byte-vectorised pass.  Cross-rank SyncBN slots an all-reduce of the
+// [2][C] sums between bn_reduce_partials_kernel and bn_finalize_kernel.
+// Backward: bn_bwd_reduce_kernel produces partials of dbeta = sum(g) and
+// dgamma = sum(g * xhat) with the ReLU mask applied on the fly, and
+// bn_bwd_apply_kernel writes dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+// (and the masked gradient for the residual branch).
+#include "common.h"
+
+// Column-reduction geometry shared by the reduce kernels: a 256-thread block
+// covers VT = min(C/EPC, 256) channel vectors x RS = 256/VT rows per pass.
+template <typename T> struct ColGeom {
+  static constexpr int EPC = 16 / sizeof(T);
+  int VT, RS, vec, rl;
+  __device__ ColGeom(int C, int cblk) {
+    const int vpr = C / EPC;
+    VT = vpr < 256 ? vpr : 256;
+    // round VT down to a power of two so RS divides 256 (C/EPC is a power of two
+    // for every ResNet width; other widths still work, just with idle lanes)
+    int p = 1;
+    while (p * 2 <= VT) p *= 2;
+    VT = p;
+    RS = 256 / VT;
+    vec = cblk * VT + (threadIdx.x % VT);
+    rl = threadIdx.x / VT;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bn_stats_partial_kernel(const T* __restrict__ y, long long M, int C, float* __restrict__ psum,
+                        float* __restrict__ psq) {
+  constexpr int EPC = 16 / sizeof(T);
+  __shared__ float red[2][256 * EPC];
+  ColGeom<T> g(C, blockIdx.y);
+  const int vpr = C / EPC;
+  float s[EPC], q[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  if (g.vec < vpr) {
+    const long long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
+    const long long r0 = blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    for (long long r = r0 + g.rl; r < r1; r += g.RS) {
+      Vec16<T> v = load16(y + r * C + (long long)g.vec * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float f = ElemTraits<T>::to_f32(v.v[e]);
+        s[e] += f;
+        q[e] += f * f;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    red[0][threadIdx.x * EPC + e] = s[e];
+    red[1][threadIdx.x * EPC + e] = q[e];
+  }
+  __syncthreads();
+  if (g.rl == 0 && g.vec < vpr) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < g.RS; ++k) {
+        a += red[0][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
+        b += red[1][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
+      }
+      psum[(long long)blockIdx.x * C + g.vec * EPC + e] = a;
+      psq[(long long)blockIdx.x * C + g.vec * EPC + e] = b;
+    }
+  }
+}
+
+// sums[0][c] = sum over partials, sums[1][c] = sum of squares (fp32 out, fp64 math)
+__global__ void bn_reduce_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                          int nparts, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)psum[(long long)p * C + c];
+    q += (double)psq[(long long)p * C + c];
+  }
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+}
+
+// One thread per channel.  count = number of reduced elements per channel (over
+// all ranks for SyncBN).  Updates running stats in place (momentum, unbiased
+// variance) and emits mean / invstd / scale / shift.
+__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
+                                   int C, double count, float eps, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)psum[(long long)p * C + c];
+    q += (double)psq[(long long)p * C + c];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - (float)mean * g * invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// Eval mode: scale/shift from running statistics.
+__global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ running_mean,
+                                      const float* __restrict__ running_var, float* __restrict__ scale_out,
+                                      float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = rsqrtf(running_var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  scale_out[c] = g * invstd;
+  shift_out[c] = b - running_mean[c] * g * invstd;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
+                const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
+                int relu) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int vpr = C / EPC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % vpr) * EPC;
+    Vec16<T> v = load16(y + i * EPC);
+    Vec16<T> rv;
+    if (res) rv = load16(res + i * EPC);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float f = ElemTraits<T>::to_f32(v.v[e]) * scale[c0 + e] + shift[c0 + e];
+      if (res) f += ElemTraits<T>::to_f32(rv.v[e]);
+      if (relu) f = fmaxf(f, 0.f);
+      o.v[e] = ElemTraits<T>::from_f32(f);
+    }
+    store16(out + i * EPC, o);
+  }
+}
+
+// g = dout masked by the ReLU of the forward (mask from `out` when given, else
+// recomputed from y*scale+shift which is exact when there was no residual).
+template <typename T>
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
+                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                     const float* __restrict__ scale, const float* __restrict__ shift, long long M, int C,
+                     int relu, float* __restrict__ pdg, float* __restrict__ pdb) {
+  constexpr int EPC = 16 / sizeof(T);
+  __shared__ float red[2][256 * EPC];
+  ColGeom<T> g(C, blockIdx.y);
+  const int vpr = C / EPC;
+  float dg[EPC], db[EPC], mu[EPC], is[EPC], sc[EPC], sf[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; sc[e] = 0.f; sf[e] = 0.f; }
+  if (g.vec < vpr) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      mu[e] = mean[g.vec * EPC + e];
+      is[e] = invstd[g.vec * EPC + e];
+      sc[e] = scale[g.vec * EPC + e];
+      sf[e] = shift[g.vec * EPC + e];
+    }
+    const long long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
+    const long long r0 = blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    for (long long r = r0 + g.rl; r < r1; r += g.RS) {
+      const long long o = r * C + (long long)g.vec * EPC;
+      Vec16<T> vd = load16(dout + o);
+      Vec16<T> vy = load16(y + o);
+      Vec16<T> vo;
+      if (relu && out) vo = load16(out + o);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float gd = ElemTraits<T>::to_f32(vd.v[e]);
+        const float yv = ElemTraits<T>::to_f32(vy.v[e]);
+        if (relu) {
+          const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * sc[e] + sf[e] > 0.f);
+          gd = pos ? gd : 0.f;
+        }
+        db[e] += gd;
+        dg[e] += gd * (yv - mu[e]) * is[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    red[0][threadIdx.x * EPC + e] = dg[e];
+    red[1][threadIdx.x * EPC + e] = db[e];
+  }
+  __syncthreads();
+  if (g.rl == 0 && g.vec < vpr) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < g.RS; ++k) {
+        a += red[0][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
+        b += red[1][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
+      }
+      pdg[(long long)blockIdx.x * C + g.vec * EPC + e] = a;
+      pdb[(long long)blockIdx.x * C + g.vec * EPC + e] = b;
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
+                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                    const float* __restrict__ dbeta, long long nvec, int C, float inv_count, int relu,
+                    T* __restrict__ dy, T* __restrict__ dres) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int vpr = C / EPC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % vpr) * EPC;
+    Vec16<T> vd = load16(dout + i * EPC);
+    Vec16<T> vy = load16(y + i * EPC);
+    Vec16<T> vo;
+    if (relu && out) vo = load16(out + i * EPC);
+    Vec16<T> o, og;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = c0 + e;
+      float gd = ElemTraits<T>::to_f32(vd.v[e]);
+      const float yv = ElemTraits<T>::to_f32(vy.v[e]);
+      if (relu) {
+        const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * scale[c] + shift[c] > 0.f);
+        gd = pos ? gd : 0.f;
+      }
+      const float xhat = (yv - mean[c]) * invstd[c];
+      const float gm = gamma ? gamma[c] : 1.f;
+      const float r = gm * invstd[c] * (gd - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count);
+      o.v[e] = ElemTraits<T>::from_f32(r);
+      og.v[e] = ElemTraits<T>::from_f32(gd);
+    }
+    store16(dy + i * EPC, o);
+    if (dres) store16(dres + i * EPC, og);
+  }
+}
+
+// out[c] = sum_p in[p][c] for two arrays at once (dgamma / dbeta partials).
+__global__ void reduce2_partials_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts,
+                                        int C, float* __restrict__ oa, float* __restrict__ ob) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    a += pa[(long long)p * C + c];
+    b += pb[(long long)p * C + c];
+  }
+  oa[c] = a;
+  ob[c] = b;
+}
+
+// ------------------------------------------------------------- host side ----
+static inline int col_blocks_y(int C, int es) {
+  const int vpr = C / (16 / es);
+  int vt = vpr < 256 ? vpr : 256;
+  int p = 1;
+  while (p * 2 <= vt) p *= 2;
+  return (vpr + p - 1) / p;
+}
+
+#define PDA_DISPATCH_T(dtype, CALL)                 \
+  switch (dtype) {                                  \
+    case PDA_F32: { typedef float T; CALL; } break; \
+    case PDA_F16: { typedef f16 T; CALL; } break;   \
+    case PDA_BF16: { typedef bf16 T; CALL; } break; \
+    default: return -6;                             \
+  }
+
+// Number of row-partials a reduce over M rows will produce (python allocates [n][C]).
+PDA_EXPORT int pda_bn_num_partials(long long M) {
+  long long n = (M + 255) / 256;
+  if (n > 512) n = 512;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+PDA_EXPORT int pda_bn_stats_partial(int dtype, const void* y, long long M, int C, float* psum, float* psq,
+                                    hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0 || ((uintptr_t)y & 15)) return -1;
+  const int nb = pda_bn_num_partials(M);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256),
+                                           0, st, (const T*)y, M, C, psum, psq));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_reduce_partials(const float* psum, const float* psq, int nparts, int C, float* sums,
+                                      hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, st, psum, psq, nparts, C,
+                     sums);
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_finalize(const float* psum, const float* psq, int nparts, int C, double count, float eps,
+                               float momentum, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float* mean_out, float* invstd_out, float* scale_out,
+                               float* shift_out, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, psum, psq, nparts, C, count,
+                     eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
+                     shift_out);
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_eval_coeffs(int C, float eps, const float* gamma, const float* beta,
+                                  const float* running_mean, const float* running_var, float* scale_out,
+                                  float* shift_out, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, eps, gamma, beta,
+                     running_mean, running_var, scale_out, shift_out);
+  return pda_check_launch();
+}
+
+static inline int ew_blocks(long long nvec) {
+  long long b = (nvec + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out, const float* scale,
+                            const float* shift, long long M, int C, int relu, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const long long nvec = M * C / (16 / es);
+  if (nvec == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(nvec)), dim3(256), 0, st,
+                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, long long M, int C,
+                                 int relu, float* pdg, float* pdb, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const int nb = pda_bn_num_partials(M);
+  PDA_DISPATCH_T(dtype,
+                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256), 0, st,
+                                    (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift, M, C,
+                                    relu, pdg, pdb));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_reduce2_partials(const float* pa, const float* pb, int nparts, int C, float* oa, float* ob,
+                                    hipStream_t st) {
+  hipLaunchKernelGGL(reduce2_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, st, pa, pb, nparts, C, oa, ob);
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, const float* gamma,
+                                const float* dgamma, const float* dbeta, long long M, int C, double count,
+                                int relu, void* dy, void* dres, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const long long nvec = M * C / (16 / es);
+  if (nvec == 0) return 0;
+  const float inv_count = (float)(1.0 / count);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(nvec)), dim3(256), 0, st,
+                                           (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift,
+                                           gamma, dgamma, dbeta, nvec, C, inv_count, relu, (T*)dy, (T*)dres));
+  return pda_check_launch();
+}

@@ -1,0 +1,684 @@
+// Implicit-GEMM convolution for gfx950 on MFMA: forward (fprop), input gradient
+// (dgrad) and weight gradient (wgrad), NHWC activations, fp16 / bf16 / fp32.
+//
+// GEMM view (reference trigger: the `model(images)` /
+// `loss.backward()` calls, /root/reference/2.distributed.py:213,231, which land
+// in cuDNN there):
+//   fprop : Y[m][n]  = sum_k A[m][k] * Wk[n][k]      m=(img,ho,wo) n=cout k=(r,s,cin)
+//   dgrad : dX[m][n] = sum_k A'[m][k] * Wt[n][k]     m=(img,hi,wi) n=cin  k=(r,s,cout)
+//   wgrad : dW[n][k] = sum_m dY[m][n] * A[m][k]      reduction over output pixels
+// A is never materialised: every 16-byte chunk of an A row is gathered straight
+// from the NHWC tensor (one (r,s) tap and BK contiguous channels per K-step).
+//
+// Tiling is for 64-lane waves: 256-thread workgroups = 4 waves in a 2x2 grid,
+// each wave owning (BM/2)x(BN/2) of the block tile as 32x32 MFMA accumulators
+// (v_mfma_f32_32x32x16_{f16,bf16}; v_mfma_f32_32x32x2_f32 for exact fp32).
+// Operand tiles are register-staged (loads for step t+1 are issued before the
+// MFMAs of step t and written to the other LDS buffer after them: one barrier
+// per K-step) and XOR-swizzled at 16-byte granularity so the ds_read_b128
+// fragment reads are bank-conflict free.  wgrad reduces over pixels, which is
+// the strided dimension of both operands, so its fragments come from
+// ds_read_b64_tr_b16 (hardware transposing LDS read) for the 16-bit types.
+#include "common.h"
+
+struct ConvArgs {
+  const void* x;    // gathered tensor (fprop: input; dgrad: dY)
+  const void* w;    // [Co][R*S*Ci], K contiguous
+  void* y;          // [M][Co]
+  const void* res;  // optional [M][Co] added in the epilogue
+  float* psum;      // optional [tiles_m][Co] per-tile column sums of the output
+  float* psq;       // optional [tiles_m][Co] per-tile column sums of squares
+  long long sn, sh, sw;  // element strides of the gathered tensor
+  int Hi, Wi, Ci;        // bounds of the gathered tensor, channels per tap
+  int Ho, Wo, Co;        // output pixels per image, GEMM N
+  int R, S;
+  int stride_h, stride_w, pad_h, pad_w;
+  int sh_log2, sw_log2;  // dgrad only (power-of-two strides)
+  int M;
+  int relu;
+};
+
+template <typename T> struct Mfma32;
+template <> struct Mfma32<f16> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32<bf16> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// rows per 256-byte LDS bank row and the chunk swizzle that spreads a 16-lane
+// ds_read_b128 group over all 64 banks.
+template <int ROWB> __device__ __forceinline__ int swz(int row) {
+  constexpr int CPR = ROWB / 16;
+  constexpr int RPB = 256 / ROWB;
+  return (row / RPB) & (CPR - 1);
+}
+
+template <typename T, int BM, int BN, int ROWB, bool DGRAD>
+__global__ void __launch_bounds__(256)
+igemm_kernel(ConvArgs a) {
+  constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
+  constexpr int BK = ROWB / sizeof(T);     // K elements per step
+  constexpr int CPR = ROWB / 16;           // chunks per tile row
+  constexpr int RPT = 256 / CPR;           // tile rows covered by one pass of 256 threads
+  constexpr int A_IT = BM / RPT;           // chunks per thread, A tile
+  constexpr int B_IT = BN / RPT;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * ROWB];
+  unsigned char* ldsA = lds;
+  unsigned char* ldsB = lds + 2 * BM * ROWB;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_n = (a.Co + BN - 1) / BN;
+  const int tiles_m = (a.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w);
+  const int Ktot = a.R * a.S * a.Ci;
+
+  const int kc = t & (CPR - 1);
+  const int trow = t / CPR;
+
+  // per-thread A rows: decompose m once, it does not change along K
+  long long abase[A_IT];
+  int ah0[A_IT], aw0[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + trow + i * RPT;
+    if (m < a.M) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw;
+      const int rem = m - n * hw;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      abase[i] = (long long)n * a.sn + kc * EPC;
+      if (DGRAD) {
+        ah0[i] = ho + a.pad_h;
+        aw0[i] = wo + a.pad_w;
+      } else {
+        ah0[i] = ho * a.stride_h - a.pad_h;
+        aw0[i] = wo * a.stride_w - a.pad_w;
+      }
+    } else {
+      abase[i] = 0;
+      ah0[i] = -(1 << 28);  // pushes every tap out of bounds
+      aw0[i] = -(1 << 28);
+    }
+  }
+  long long bbase[B_IT];
+  bool bok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + trow + i * RPT;
+    bok[i] = n < a.Co;
+    bbase[i] = (long long)n * Ktot + kc * EPC;
+  }
+
+  u32x4 ra[A_IT], rb[B_IT];
+  int r = 0, s = 0, c0 = 0, kofs = 0;
+
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int hi, wi;
+      bool ok;
+      if (DGRAD) {
+        const int hn = ah0[i] - r, wn_ = aw0[i] - s;
+        ok = ((hn & (a.stride_h - 1)) == 0) && ((wn_ & (a.stride_w - 1)) == 0);
+        hi = hn >> a.sh_log2;
+        wi = wn_ >> a.sw_log2;
+      } else {
+        hi = ah0[i] + r;
+        wi = aw0[i] + s;
+        ok = true;
+      }
+      ok = ok && ((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const long long off = abase[i] + (long long)hi * a.sh + (long long)wi * a.sw + c0;
+        v = *reinterpret_cast<const u32x4*>(X + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (bok[i]) v = *reinterpret_cast<const u32x4*>(Wt + bbase[i] + kofs);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = trow + i * RPT;
+      *reinterpret_cast<u32x4*>(ldsA + buf * BM * ROWB + row * ROWB + ((kc ^ swz<ROWB>(row)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int row = trow + i * RPT;
+      *reinterpret_cast<u32x4*>(ldsB + buf * BN * ROWB + row * ROWB + ((kc ^ swz<ROWB>(row)) << 4)) = rb[i];
+    }
+  };
+  auto advance = [&]() {
+    kofs += BK;
+    c0 += BK;
+    if (c0 >= a.Ci) {
+      c0 = 0;
+      if (++s >= a.S) { s = 0; ++r; }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  const int nk = a.R * a.S * (a.Ci / BK);
+  gload();
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      advance();
+      gload();
+    }
+    const unsigned char* A_ = ldsA + (kt & 1) * BM * ROWB;
+    const unsigned char* B_ = ldsB + (kt & 1) * BN * ROWB;
+    if constexpr (sizeof(T) == 2) {
+      typedef typename Mfma32<T>::frag frag;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        frag fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WTM + i * 32 + l31;
+          fa[i] = *reinterpret_cast<const frag*>(A_ + row * ROWB + (((kk * 2 + lh) ^ swz<ROWB>(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int row = wn * WTN + j * 32 + l31;
+          fb[j] = *reinterpret_cast<const frag*>(B_ + row * ROWB + (((kk * 2 + lh) ^ swz<ROWB>(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[i], fb[j], acc[i][j]);
+      }
+    } else {
+      // fp32: one 16-byte chunk = 4 k values; lane half h owns k = 2h, 2h+1 of
+      // the chunk (any k permutation is fine as long as A and B agree).
+#pragma unroll
+      for (int c = 0; c < CPR; ++c) {
+        f32x2 fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WTM + i * 32 + l31;
+          fa[i] = *reinterpret_cast<const f32x2*>(A_ + row * ROWB + ((c ^ swz<ROWB>(row)) << 4) + lh * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int row = wn * WTN + j * 32 + l31;
+          fb[j] = *reinterpret_cast<const f32x2*>(B_ + row * ROWB + ((c ^ swz<ROWB>(row)) << 4) + lh * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+    if (more) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (g&3)+8*(g>>2)+4*(lane>>5)
+  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
+  const T* __restrict__ Rz = reinterpret_cast<const T*>(a.res);
+  const bool stats = a.psum != nullptr;
+  float csum[NI], csq[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+        float v = acc[i][j][g];
+        const bool ok = (m < a.M) && (n < a.Co);
+        const long long o = (long long)m * a.Co + n;
+        if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
+        if (a.relu) v = fmaxf(v, 0.f);
+        const T tv = ElemTraits<T>::from_f32(v);
+        if (ok) Y[o] = tv;
+        if (stats) {
+          // statistics of the value as stored, so mean/var describe the tensor
+          // that the normalisation pass will read back
+          const float fv = ok ? ElemTraits<T>::to_f32(tv) : 0.f;
+          csum[j] += fv;
+          csq[j] += fv * fv;
+        }
+      }
+    }
+
+  if (stats) {
+    float* sred = reinterpret_cast<float*>(lds);  // [2 wm][BN][2]; tiles are dead after the last barrier
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (lh == 0) {
+        const int col = wn * WTN + j * 32 + l31;
+        sred[(wm * BN + col) * 2 + 0] = s1;
+        sred[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < a.Co) {
+      a.psum[(long long)tm * a.Co + n0 + t] = sred[t * 2] + sred[(BN + t) * 2];
+      a.psq[(long long)tm * a.Co + n0 + t] = sred[t * 2 + 1] + sred[(BN + t) * 2 + 1];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- wgrad ----
+struct WgradArgs {
+  const void* dy;  // [M][Co]
+  const void* x;   // gathered input
+  float* dw;       // [Co][Ktot] fp32, accumulated with float atomics
+  long long sn, sh, sw;
+  int Hi, Wi, Ci;
+  int Ho, Wo, Co;
+  int R, S, stride_h, stride_w, pad_h, pad_w;
+  int M, Ktot;
+  int pix_per_split;  // multiple of the pixel step
+};
+
+template <typename T> struct TrRead;
+template <> struct TrRead<f16> {
+  static __device__ __forceinline__ f16x8 read(const unsigned char* p0, const unsigned char* p1) {
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p1));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, v);
+  }
+};
+template <> struct TrRead<bf16> {
+  static __device__ __forceinline__ bf16x8 read(const unsigned char* p0, const unsigned char* p1) {
+    typedef s16x4 __attribute__((address_space(3))) * lp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p1));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
+// 64-byte-segment swizzle of a [pixel][channel] image so the four pixel rows of
+// one transposed read fall on four different quarters of the 256-byte bank row.
+template <int PITCH> __device__ __forceinline__ int trswz(int px) {
+  if constexpr (PITCH % 256 == 0) return (px & 3) << 6;
+  else if constexpr (PITCH == 128) return ((px >> 1) & 1) << 6;
+  else return 0;
+}
+
+template <typename T, int TM, int TN, int BKP>
+__global__ void __launch_bounds__(256)
+wgrad_kernel(WgradArgs a) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int PY = TM * sizeof(T), PX = TN * sizeof(T);  // LDS row pitches (bytes)
+  constexpr int CPY = PY / 16, CPX = PX / 16;              // chunks per pixel row
+  constexpr int RPY = 256 / CPY, RPX = 256 / CPX;          // pixel rows per pass
+  constexpr int Y_IT = (BKP + RPY - 1) / RPY, X_IT = (BKP + RPX - 1) / RPX;
+  constexpr int WTM = TM / 2, WTN = TN / 2;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1, "tile too small");
+  static_assert(CPY <= 256 && CPX <= 256, "tile too wide");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BKP * (PY + PX)];
+  unsigned char* ldsY = lds;
+  unsigned char* ldsX = lds + 2 * BKP * PY;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tiles_k = (a.Co + TM - 1) / TM;
+  const int tk = blockIdx.x % tiles_k, tc = blockIdx.x / tiles_k;
+  const int k0 = tk * TM, c0n = tc * TN;
+  const int mbeg = blockIdx.y * a.pix_per_split;
+  const int mend = min(a.M, mbeg + a.pix_per_split);
+
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+
+  // dY loader: chunk column fixed per thread
+  const int ycc = t % CPY, ypx = t / CPY;
+  const bool yok_c = (k0 + ycc * EPC) < a.Co;
+  // X loader: chunk column -> (r, s, c) fixed per thread
+  const int xcc = t % CPX, xpx = t / CPX;
+  const int kidx = c0n + xcc * EPC;
+  const bool xok_c = kidx < a.Ktot;
+  int xr = 0, xs = 0, xc = 0;
+  if (xok_c) {
+    const int sc = a.S * a.Ci;
+    xr = kidx / sc;
+    const int rem = kidx - xr * sc;
+    xs = rem / a.Ci;
+    xc = rem - xs * a.Ci;
+  }
+  const int hw = a.Ho * a.Wo;
+
+  u32x4 ry[Y_IT], rx[X_IT];
+  auto gload = [&](int mstep) {
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int px = ypx + i * RPY;
+      const int m = mstep + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (px < BKP && m < mend && yok_c)
+        v = *reinterpret_cast<const u32x4*>(DY + (long long)m * a.Co + k0 + ycc * EPC);
+      ry[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int px = xpx + i * RPX;
+      const int m = mstep + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (px < BKP && m < mend && xok_c) {
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        const int hi = ho * a.stride_h - a.pad_h + xr;
+        const int wi = wo * a.stride_w - a.pad_w + xs;
+        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+          v = *reinterpret_cast<const u32x4*>(X + (long long)n * a.sn + (long long)hi * a.sh +
+                                              (long long)wi * a.sw + xc);
+      }
+      rx[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int px = ypx + i * RPY;
+      if (px < BKP) {
+        const int bo = (sizeof(T) == 2) ? ((ycc * 16) ^ trswz<PY>(px)) : ycc * 16;
+        *reinterpret_cast<u32x4*>(ldsY + buf * BKP * PY + px * PY + bo) = ry[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int px = xpx + i * RPX;
+      if (px < BKP) {
+        const int bo = (sizeof(T) == 2) ? ((xcc * 16) ^ trswz<PX>(px)) : xcc * 16;
+        *reinterpret_cast<u32x4*>(ldsX + buf * BKP * PX + px * PX + bo) = rx[i];
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  const int nsteps = (mend > mbeg) ? (mend - mbeg + BKP - 1) / BKP : 0;
+  if (nsteps > 0) {
+    gload(mbeg);
+    lstore(0);
+  }
+  __syncthreads();
+
+  const int li = lane & 15, lg = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const bool more = st + 1 < nsteps;
+    if (more) gload(mbeg + (st + 1) * BKP);
+    const unsigned char* Yb = ldsY + (st & 1) * BKP * PY;
+    const unsigned char* Xb = ldsX + (st & 1) * BKP * PX;
+    if constexpr (sizeof(T) == 2) {
+      typedef typename Mfma32<T>::frag frag;
+#pragma unroll
+      for (int kk = 0; kk < BKP / 16; ++kk) {
+        // 16-lane group lg: channel sub-block 16*(lg&1), pixel rows 8*(lg>>1)+{0..3},{4..7};
+        // lane 4q+p of a group addresses pixel row q, channels 4p..4p+3 and
+        // receives channel (lane&15) of the four rows.
+        const int prow = kk * 16 + 8 * (lg >> 1) + (li >> 2);
+        frag fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int col = wm * WTM + i * 32 + 16 * (lg & 1) + 4 * (li & 3);
+          const unsigned char* p0 = Yb + prow * PY + ((col * 2) ^ trswz<PY>(prow));
+          const unsigned char* p1 = Yb + (prow + 4) * PY + ((col * 2) ^ trswz<PY>(prow + 4));
+          fa[i] = TrRead<T>::read(p0, p1);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = wn * WTN + j * 32 + 16 * (lg & 1) + 4 * (li & 3);
+          const unsigned char* p0 = Xb + prow * PX + ((col * 2) ^ trswz<PX>(prow));
+          const unsigned char* p1 = Xb + (prow + 4) * PX + ((col * 2) ^ trswz<PX>(prow + 4));
+          fb[j] = TrRead<T>::read(p0, p1);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[i], fb[j], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BKP / 2; ++kk) {
+        const int prow = kk * 2 + lh;
+        float fa[MI], fb[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          fa[i] = *reinterpret_cast<const float*>(Yb + prow * PY + (wm * WTM + i * 32 + l31) * 4);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fb[j] = *reinterpret_cast<const float*>(Xb + prow * PX + (wn * WTN + j * 32 + l31) * 4);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (more) lstore((st + 1) & 1);
+    __syncthreads();
+  }
+
+  if (nsteps == 0) return;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = c0n + wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = k0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+        if (row < a.Co && col < a.Ktot) atomicAdd(a.dw + (long long)row * a.Ktot + col, acc[i][j][g]);
+      }
+    }
+}
+
+// ------------------------------------------------------- weight layouts ----
+// out[c][r][s][k] = in[k][r][s][c]  (KRSC -> CRSK, the dgrad B operand), with cast.
+template <typename TI, typename TO>
+__global__ void krsc_to_crsk_kernel(const TI* __restrict__ in, TO* __restrict__ out, int K, int RS, int C) {
+  const long long total = (long long)K * RS * C;
+  for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+       o += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(o % K);
+    const long long t2 = o / K;
+    const int rs = (int)(t2 % RS);
+    const int c = (int)(t2 / RS);
+    out[o] = ElemTraits<TO>::from_f32(ElemTraits<TI>::to_f32(in[((long long)k * RS + rs) * C + c]));
+  }
+}
+
+// ------------------------------------------------------------- host side ----
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}
+
+template <typename T, int BM, int BN, int ROWB>
+static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
+  if (dgrad)
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, true>), dim3(tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, false>), dim3(tiles), dim3(256), 0, st, a);
+  return pda_check_launch();
+}
+
+// cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64; bit 3 forces 64-byte K rows.
+static int pick_tile(int M, int Co, int cfg) {
+  int tile = cfg & 7;
+  if (tile == 0) {
+    const long long t128 = (long long)((M + 127) / 128) * ((Co + 127) / 128);
+    if (Co <= 64) tile = 2;
+    else if (t128 < 192 && M >= 64) tile = (Co % 128 == 0 && t128 * 2 >= 192) ? 2 : 3;
+    else tile = 1;
+  }
+  return tile;
+}
+
+template <typename T>
+static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st) {
+  constexpr int ES = sizeof(T);
+  const bool k128 = (a.Ci % (128 / ES)) == 0;
+  const bool k64 = (a.Ci % (64 / ES)) == 0;
+  if (!k64) return -1;
+  const bool use128 = k128 && (cfg & 8) == 0;
+  switch (pick_tile(a.M, a.Co, cfg)) {
+    case 1: return use128 ? launch_igemm<T, 128, 128, 128>(a, dgrad, st) : launch_igemm<T, 128, 128, 64>(a, dgrad, st);
+    case 2: return use128 ? launch_igemm<T, 128, 64, 128>(a, dgrad, st) : launch_igemm<T, 128, 64, 64>(a, dgrad, st);
+    case 3: return use128 ? launch_igemm<T, 64, 64, 128>(a, dgrad, st) : launch_igemm<T, 64, 64, 64>(a, dgrad, st);
+    default: return -2;
+  }
+}
+
+// Block-tile rows used for a given cfg/shape (python sizes the stats partials with it).
+PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) { return pick_tile(M, Co, cfg) == 3 ? 64 : 128; }
+
+// Returns 0 on success, <0 if the shape is not covered by the MFMA kernels
+// (caller falls back to the direct kernels), >0 = hipError_t.
+PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
+                              float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                              long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int relu, int cfg, hipStream_t stream) {
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.res = res; a.psum = psum; a.psq = psq;
+  a.sn = sn; a.sh = sh; a.sw = sw;
+  a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co;
+  a.R = R; a.S = S; a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.sh_log2 = ilog2_exact(stride_h); a.sw_log2 = ilog2_exact(stride_w);
+  a.M = N * Ho * Wo; a.relu = relu;
+  if (a.M <= 0 || Co <= 0) return 0;
+  if (dgrad && (a.sh_log2 < 0 || a.sw_log2 < 0)) return -3;
+  if ((long long)N * Ho * Wo > 0x7fffffffLL) return -4;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -5;
+  switch (dtype) {
+    case PDA_F16: return dispatch_igemm<f16>(a, dgrad, cfg, stream);
+    case PDA_BF16: return dispatch_igemm<bf16>(a, dgrad, cfg, stream);
+    case PDA_F32: return dispatch_igemm<float>(a, dgrad, cfg, stream);
+    default: return -6;
+  }
+}
+
+template <typename T, int TM, int TN, int BKP>
+static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
+  const int tiles = ((a.Co + TM - 1) / TM) * ((a.Ktot + TN - 1) / TN);
+  int nsplit = nsplit_hint;
+  if (nsplit <= 0) {
+    nsplit = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
+    const int maxsplit = (a.M + 4 * BKP - 1) / (4 * BKP);
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  int pps = (a.M + nsplit - 1) / nsplit;
+  pps = ((pps + BKP - 1) / BKP) * BKP;
+  nsplit = (a.M + pps - 1) / pps;
+  a.pix_per_split = pps;
+  hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+  return pda_check_launch();
+}
+
+// dw must be zero-initialised (or hold the gradient to accumulate into).
+PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int Hi, int Wi, int Ci,
+                              long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
+                              int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int nsplit,
+                              hipStream_t stream) {
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.dw = dw; a.sn = sn; a.sh = sh; a.sw = sw;
+  a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.R = R; a.S = S;
+  a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
+  a.M = N * Ho * Wo; a.Ktot = R * S * Ci; a.pix_per_split = 0;
+  if (a.M <= 0) return 0;
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  const int epc = 16 / es;
+  if (Ci % epc != 0 || Co % epc != 0) return -1;
+  if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return -5;
+  int tile = cfg & 7;
+  if (tile == 0) tile = (Co % 128 == 0 && a.Ktot % 128 == 0 && Co >= 128) ? 1 : 2;
+  switch (dtype) {
+    case PDA_F16:
+      return tile == 1 ? launch_wgrad<f16, 128, 128, 32>(a, nsplit, stream)
+                       : launch_wgrad<f16, 64, 64, 32>(a, nsplit, stream);
+    case PDA_BF16:
+      return tile == 1 ? launch_wgrad<bf16, 128, 128, 32>(a, nsplit, stream)
+                       : launch_wgrad<bf16, 64, 64, 32>(a, nsplit, stream);
+    case PDA_F32:
+      return tile == 1 ? launch_wgrad<float, 128, 128, 16>(a, nsplit, stream)
+                       : launch_wgrad<float, 64, 64, 16>(a, nsplit, stream);
+    default: return -6;
+  }
+}
+
+PDA_EXPORT int pda_krsc_to_crsk(int dt_in, int dt_out, const void* in, void* out, int K, int RS, int C,
+                                hipStream_t stream) {
+  const long long total = (long long)K * RS * C;
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+#define PDA_T(TI, TO) \
+  hipLaunchKernelGGL((krsc_to_crsk_kernel<TI, TO>), dim3(blocks), dim3(256), 0, stream, (const TI*)in, (TO*)out, K, RS, C)
+  if (dt_in == PDA_F32 && dt_out == PDA_F32) PDA_T(float, float);
+  else if (dt_in == PDA_F32 && dt_out == PDA_F16) PDA_T(float, f16);
+  else if (dt_in == PDA_F32 && dt_out == PDA_BF16) PDA_T(float, bf16);
+  else if (dt_in == PDA_F16 && dt_out == PDA_F16) PDA_T(f16, f16);
+  else if (dt_in == PDA_BF16 && dt_out == PDA_BF16) PDA_T(bf16, bf16);
+  else return -6;
+#undef PDA_T
+  return pda_check_launch();
+}

@@ -1,0 +1,191 @@
+// Memory-bound element-wise kernels:
+//  * input pipeline: NCHW (uint8 / fp32 / fp16) -> NHWC compute dtype with the
+//    per-channel (x - mean) / std of the loader fused in, optional channel
+//    padding (the ResNet stem wants 4 channels) and an optional zero border
+//    (reference: `images.cuda(non_blocking=True)` + the data_prefetcher's
+//    `.float().sub_(mean).div_(std)`, /root/reference/4.apex_distributed.py:119-122);
+//  * stand-alone ReLU fwd/bwd, add, per-channel bias add (MNIST net);
+//  * dropout / channel dropout with a counter-based Philox stream, so the mask
+//    is regenerated in backward instead of stored
+//    (reference: nn.Dropout2d / F.dropout, /root/reference/5.2.horovod_pytorch_mnist.py:41,47,50).
+#include "common.h"
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const TI* __restrict__ in, TO* __restrict__ out, int N, int C, int H, int W, int Cp, int Hp,
+                    int Wp, int oh, int ow, const float* __restrict__ mean, const float* __restrict__ inv_std,
+                    float pre_scale) {
+  // one thread per output pixel (all Cp channels): reads are strided by H*W but
+  // consecutive threads read consecutive w, so each channel plane is coalesced.
+  const long long total = (long long)N * Hp * Wp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int wp = (int)(i % Wp);
+    long long r = i / Wp;
+    const int hp = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const int h = hp - oh, w = wp - ow;
+    const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    TO* o = out + i * Cp;
+    for (int c = 0; c < Cp; ++c) {
+      float v = 0.f;
+      if (inside && c < C) {
+        v = (float)in[(((long long)n * C + c) * H + h) * W + w] * pre_scale;
+        if (mean) v = (v - mean[c]) * inv_std[c];
+      }
+      o[c] = ElemTraits<TO>::from_f32(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+relu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(x[i]), 0.f));
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = ElemTraits<T>::to_f32(y[i]) > 0.f ? dy[i] : ElemTraits<T>::from_f32(0.f);
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n, int relu) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = ElemTraits<T>::to_f32(a[i]) + ElemTraits<T>::to_f32(b[i]);
+    if (relu) v = fmaxf(v, 0.f);
+    o[i] = ElemTraits<T>::from_f32(v);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+bias_add_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, long long n, int C,
+                int relu) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = ElemTraits<T>::to_f32(x[i]) + bias[i % C];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = ElemTraits<T>::from_f32(v);
+  }
+}
+// dbias[c] = sum over rows of dy[m][c]   (any C; one block per 64 channels)
+template <typename T>
+__global__ void __launch_bounds__(256)
+colsum_kernel(const T* __restrict__ dy, float* __restrict__ out, long long M, int C) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (long long m = rl; m < M; m += 4) acc += ElemTraits<T>::to_f32(dy[m * C + c]);
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ---- Philox4x32-10 ---------------------------------------------------------
+struct Philox {
+  unsigned int k0, k1;
+  __device__ Philox(unsigned long long seed) : k0((unsigned)seed), k1((unsigned)(seed >> 32)) {}
+  __device__ void operator()(unsigned long long ctr_lo, unsigned long long ctr_hi, unsigned int (&out)[4]) const {
+    unsigned int c0 = (unsigned)ctr_lo, c1 = (unsigned)(ctr_lo >> 32), c2 = (unsigned)ctr_hi, c3 = (unsigned)(ctr_hi >> 32);
+    unsigned int a = k0, b = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+      const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+      const unsigned int n0 = (unsigned)(p1 >> 32) ^ c1 ^ a;
+      const unsigned int n1 = (unsigned)p1;
+      const unsigned int n2 = (unsigned)(p0 >> 32) ^ c3 ^ b;
+      const unsigned int n3 = (unsigned)p0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+};
+
+// y = x * mask / (1-p); mask element index = i (element mode) or (n, c) (channel
+// mode, NHWC: every pixel of one image shares the channel's mask).  The same
+// (seed, offset) regenerates the mask for backward.
+template <typename T>
+__global__ void __launch_bounds__(256)
+dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p, unsigned long long seed,
+               unsigned long long offset, int channel_mode, long long per_image, int C) {
+  Philox rng(seed);
+  const float keep_scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long id = channel_mode ? (i / per_image) * C + (i % C) : i;
+    unsigned int r[4];
+    rng((unsigned long long)(id >> 2), offset, r);
+    const float u = (float)(r[id & 3] >> 8) * (1.0f / 16777216.0f);
+    const float v = u >= p ? ElemTraits<T>::to_f32(x[i]) * keep_scale : 0.f;
+    y[i] = ElemTraits<T>::from_f32(v);
+  }
+}
+
+static inline int ew_blocks(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define PDA_DISPATCH_T(dtype, CALL)                 \
+  switch (dtype) {                                  \
+    case PDA_F32: { typedef float T; CALL; } break; \
+    case PDA_F16: { typedef f16 T; CALL; } break;   \
+    case PDA_BF16: { typedef bf16 T; CALL; } break; \
+    default: return -6;                             \
+  }
+
+// dt_in: 0 fp32, 1 fp16, 3 uint8
+PDA_EXPORT int pda_nchw_to_nhwc(int dt_in, int dt_out, const void* in, void* out, int N, int C, int H, int W, int Cp,
+                                int Hp, int Wp, int oh, int ow, const float* mean, const float* inv_std,
+                                float pre_scale, hipStream_t st) {
+  const long long total = (long long)N * Hp * Wp;
+  if (total == 0) return 0;
+  const int nb = ew_blocks(total);
+#define L_CVT(TI) \
+  PDA_DISPATCH_T(dt_out, hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, T>), dim3(nb), dim3(256), 0, st, (const TI*)in, \
+                                            (T*)out, N, C, H, W, Cp, Hp, Wp, oh, ow, mean, inv_std, pre_scale))
+  if (dt_in == 0) { L_CVT(float); }
+  else if (dt_in == 1) { L_CVT(f16); }
+  else if (dt_in == 3) { L_CVT(unsigned char); }
+  else return -6;
+#undef L_CVT
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_relu_fwd(int dtype, const void* x, void* y, long long n, hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_add(int dtype, const void* a, const void* b, void* o, long long n, int relu, hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)a, (const T*)b, (T*)o, n, relu));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_bias_add(int dtype, const void* x, const float* bias, void* y, long long n, int C, int relu,
+                            hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bias_add_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, C, relu));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_colsum(int dtype, const void* dy, float* out, long long M, int C, hipStream_t st) {
+  if (C == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3((C + 63) / 64), dim3(256), 0, st, (const T*)dy, out, M, C));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_dropout(int dtype, const void* x, void* y, long long n, float p, unsigned long long seed,
+                           unsigned long long offset, int channel_mode, long long per_image, int C, hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n, p, seed, offset, channel_mode, per_image, C));
+  return pda_check_launch();
+}

@@ -1,0 +1,208 @@
+// Pooling for NHWC activations: max-pool (any window/stride/pad; ResNet stem
+// 3x3 s2 p1 and the 2x2 pools of the MNIST net) with a saved arg-max byte so the
+// backward is a gather, and global average pooling (reference
+// triggers: torchvision ResNet maxpool/avgpool under
+// /root/reference/2.distributed.py:213 and F.max_pool2d in
+// /root/reference/5.2.horovod_pytorch_mnist.py:46-47).
+#include "common.h"
+
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ idx, int N, int H,
+                   int W, int C, int Ho, int Wo, int k, int s, int p) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * Ho * Wo * vpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    long long r = i / vpr;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best[EPC];
+    unsigned char bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int a = 0; a < k; ++a) {
+      const int h = ho * s - p + a;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int w = wo * s - p + b;
+        if ((unsigned)w >= (unsigned)W) continue;
+        VecN<T, EPC> v = loadN<T, EPC>(x + (((long long)n * H + h) * W + w) * C + cv * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float f = ElemTraits<T>::to_f32(v.v[e]);
+          if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(a * k + b); }
+        }
+      }
+    }
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(best[e]);
+    storeN<T, EPC>(out + i * EPC, o);
+    if (idx) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) idx[i * EPC + e] = bi[e];
+    }
+  }
+}
+
+// One thread per input pixel-vector: sum the output gradients of every window
+// whose arg-max byte points back at this pixel (no atomics, deterministic).
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx, T* __restrict__ dx, int N,
+                   int H, int W, int C, int Ho, int Wo, int k, int s, int p) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * H * W * vpr;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    long long r = i / vpr;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    // windows ho with ho*s - p <= h <= ho*s - p + k - 1
+    int ho_lo = (h + p - k + 1 + s - 1);
+    ho_lo = ho_lo < 0 ? 0 : ho_lo / s;
+    int ho_hi = (h + p) / s;
+    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+    int wo_lo = (w + p - k + 1 + s - 1);
+    wo_lo = wo_lo < 0 ? 0 : wo_lo / s;
+    int wo_hi = (w + p) / s;
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int a = h - (ho * s - p), b = w - (wo * s - p);
+        const unsigned char me = (unsigned char)(a * k + b);
+        const long long o = ((((long long)n * Ho + ho) * Wo + wo) * vpr + cv) * EPC;
+        VecN<T, EPC> g = loadN<T, EPC>(dout + o);
+        unsigned char ib[EPC];
+        if constexpr (EPC == 8) {
+          *reinterpret_cast<u32x2*>(ib) = *reinterpret_cast<const u32x2*>(idx + o);
+        } else if constexpr (EPC == 4) {
+          *reinterpret_cast<unsigned int*>(ib) = *reinterpret_cast<const unsigned int*>(idx + o);
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) ib[e] = idx[o + e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (ib[e] == me) acc[e] += ElemTraits<T>::to_f32(g.v[e]);
+      }
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e]);
+    storeN<T, EPC>(dx + i * EPC, o);
+  }
+}
+
+// out[n][c] = mean over HW of x[n][hw][c]   (fp32 accumulate)
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+gap_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int HW, int C) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * vpr;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    const long long n = i / vpr;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      VecN<T, EPC> v = loadN<T, EPC>(x + (n * HW + p) * C + cv * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += ElemTraits<T>::to_f32(v.v[e]);
+    }
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e] * inv);
+    storeN<T, EPC>(out + i * EPC, o);
+  }
+}
+
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+gap_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int N, int HW, int C) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * HW * vpr;
+  const float inv = 1.f / (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    const long long n = i / ((long long)HW * vpr);
+    VecN<T, EPC> g = loadN<T, EPC>(dout + (n * vpr + cv) * EPC);
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(g.v[e]) * inv);
+    storeN<T, EPC>(dx + i * EPC, o);
+  }
+}
+
+static inline int ew_blocks(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+// VEC = elements per lane: a full 16-byte vector when C allows it, else 1.
+#define PDA_DISPATCH_TV(dtype, vec, CALL)                                        \
+  switch (dtype) {                                                               \
+    case PDA_F32: { typedef float T; if (vec) { constexpr int EPC = 4; CALL; } else { constexpr int EPC = 1; CALL; } } break; \
+    case PDA_F16: { typedef f16 T; if (vec) { constexpr int EPC = 8; CALL; } else { constexpr int EPC = 1; CALL; } } break;   \
+    case PDA_BF16: { typedef bf16 T; if (vec) { constexpr int EPC = 8; CALL; } else { constexpr int EPC = 1; CALL; } } break; \
+    default: return -6;                                                          \
+  }
+
+PDA_EXPORT int pda_maxpool_fwd(int dtype, const void* x, void* out, unsigned char* idx, int N, int H, int W, int C,
+                               int Ho, int Wo, int k, int s, int p, hipStream_t st) {
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  const bool vec = (C % epc) == 0;
+  if (!vec) epc = 1;
+  if (k * k > 255) return -1;
+  const long long total = (long long)N * Ho * Wo * (C / epc);
+  if (total == 0) return 0;
+  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_fwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                           (const T*)x, (T*)out, idx, N, H, W, C, Ho, Wo, k, s, p));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_maxpool_bwd(int dtype, const void* dout, const unsigned char* idx, void* dx, int N, int H, int W,
+                               int C, int Ho, int Wo, int k, int s, int p, hipStream_t st) {
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  const bool vec = (C % epc) == 0;
+  if (!vec) epc = 1;
+  const long long total = (long long)N * H * W * (C / epc);
+  if (total == 0) return 0;
+  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_bwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                           (const T*)dout, idx, (T*)dx, N, H, W, C, Ho, Wo, k, s, p));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_gap_fwd(int dtype, const void* x, void* out, int N, int HW, int C, hipStream_t st) {
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  const bool vec = (C % epc) == 0;
+  if (!vec) epc = 1;
+  const long long total = (long long)N * (C / epc);
+  if (total == 0) return 0;
+  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((gap_fwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                           (const T*)x, (T*)out, N, HW, C));
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_gap_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, hipStream_t st) {
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  const bool vec = (C % epc) == 0;
+  if (!vec) epc = 1;
+  const long long total = (long long)N * HW * (C / epc);
+  if (total == 0) return 0;
+  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((gap_bwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                           (const T*)dout, (T*)dx, N, HW, C));
+  return pda_check_launch();
+}

@@ -1,0 +1,38 @@
+"""Model zoo.  ``models.__dict__[arch]()`` / ``models.get_model(arch)`` mirror the
+reference's ``torchvision.models.__dict__[args.arch](pretrained=...)`` factory and
+``model_names`` its ``--arch`` choices (/root/reference/1.dataparallel.py:23-24,97-102).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .resnet import ResNet, BasicBlock, Bottleneck, resnet18, resnet34, resnet50, resnet101, resnet152
+from .mnist import Net, mnist_net
+from .reference import torch_resnet, TorchResNet
+
+model_names = sorted(["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "mnist_net"])
+
+
+def get_model(arch: str, pretrained: bool = False, **kw):
+    if arch not in model_names:
+        raise ValueError(f"unknown arch {arch!r}; choices: {', '.join(model_names)}")
+    return globals()[arch](pretrained=pretrained, **kw)
+
+
+def load_pretrained(model, arch: str) -> None:
+    """There is no network here: ``--pretrained`` loads ``$PDA_PRETRAINED_DIR/<arch>.pth``
+    (a torchvision-format state_dict) if present and raises otherwise."""
+    root = os.environ.get("PDA_PRETRAINED_DIR", "")
+    path = os.path.join(root, f"{arch}.pth")
+    if not root or not os.path.exists(path):
+        raise FileNotFoundError(
+            f"pretrained weights for {arch} requested but {path!r} does not exist "
+            "(set PDA_PRETRAINED_DIR to a directory of torchvision state_dicts; nothing is downloaded)")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    model.load_state_dict(sd.get("state_dict", sd))
+
+
+__all__ = ["ResNet", "BasicBlock", "Bottleneck", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152",
+           "Net", "mnist_net", "torch_resnet", "TorchResNet", "model_names", "get_model", "load_pretrained"]

@@ -1,0 +1,179 @@
+"""ResNet-18/34/50/101/152 (torchvision v1.5 topology: stride on the 3x3 of a
+bottleneck) built on the fused NHWC ops.
+
+``state_dict()`` keys, shapes and dtypes are those of torchvision's ResNet
+(``conv1.weight``, ``layer1.0.bn1.running_mean``, ``layer2.0.downsample.0.weight``,
+``fc.bias`` ...), so checkpoints move freely between this model and the stock one.
+The reference builds these through ``models.__dict__[args.arch]()`` with the
+default 1000-class head even for CIFAR-10 (/root/reference/1.dataparallel.py:97-102,
+/root/reference/2.distributed.py:100-105).
+
+Forward takes the loader's NCHW batch (fp32, fp16 or uint8).  On the GPU the stem
+op does the layout change, normalisation and cast in one kernel; everything after
+it runs NHWC in ``compute_dtype`` (fp32 by default; ``model.set_compute_dtype(torch.float16)``
+or ``amp.initialize`` for mixed precision) with fp32 master parameters.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Type, Union
+
+import torch
+import torch.nn as tnn
+
+from .. import nn as pnn
+from .. import ops
+
+
+def _conv3x3(cin, cout, stride=1):
+    return pnn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+
+
+def _conv1x1(cin, cout, stride=1):
+    return pnn.Conv2d(cin, cout, 1, stride, 0, bias=False)
+
+
+class BasicBlock(tnn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, planes, stride)
+        self.bn1 = pnn.BatchNorm2d(planes)
+        self.relu = pnn.ReLU()
+        self.conv2 = _conv3x3(planes, planes)
+        self.bn2 = pnn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True)
+        if self.downsample is not None:
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], x, relu=False)
+        return pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, residual=identity)
+
+
+class Bottleneck(tnn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None):
+        super().__init__()
+        self.conv1 = _conv1x1(inplanes, planes)
+        self.bn1 = pnn.BatchNorm2d(planes)
+        self.conv2 = _conv3x3(planes, planes, stride)
+        self.bn2 = pnn.BatchNorm2d(planes)
+        self.conv3 = _conv1x1(planes, planes * self.expansion)
+        self.bn3 = pnn.BatchNorm2d(planes * self.expansion)
+        self.relu = pnn.ReLU()
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True)
+        out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True)
+        if self.downsample is not None:
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], x, relu=False)
+        return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity)
+
+
+class ResNet(tnn.Module):
+    def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], num_classes: int = 1000,
+                 zero_init_residual: bool = False, input_mean=None, input_std=None, input_scale: float = 1.0):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = pnn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = pnn.BatchNorm2d(64)
+        self.relu = pnn.ReLU()
+        self.maxpool = pnn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = pnn.GlobalAvgPool2d()
+        self.fc = pnn.Linear(512 * block.expansion, num_classes)
+        self.compute_dtype = torch.float32
+        # optional on-device input normalisation (what the reference's data_prefetcher does
+        # on its side stream, /root/reference/4.apex_distributed.py:85-86,121-122)
+        if input_mean is not None:
+            self.register_buffer("_in_mean", torch.tensor(input_mean, dtype=torch.float32), persistent=False)
+            self.register_buffer("_in_inv_std", 1.0 / torch.tensor(input_std, dtype=torch.float32), persistent=False)
+        else:
+            self._in_mean = None
+            self._in_inv_std = None
+        self.input_scale = input_scale
+
+        for m in self.modules():
+            if isinstance(m, pnn.Conv2d):
+                tnn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, pnn.BatchNorm2d):
+                tnn.init.constant_(m.weight, 1)
+                tnn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    tnn.init.constant_(m.bn3.weight, 0)
+                elif isinstance(m, BasicBlock):
+                    tnn.init.constant_(m.bn2.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = tnn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
+                                        pnn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return tnn.Sequential(*layers)
+
+    def set_compute_dtype(self, dtype: torch.dtype) -> "ResNet":
+        """Activation / MFMA input dtype (fp32, fp16 or bf16); parameters stay fp32 masters."""
+        assert dtype in (torch.float32, torch.float16, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def features(self, images: torch.Tensor) -> torch.Tensor:
+        x = ops.stem_conv_bn_relu_pool(images, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv1.stride,
+                                       self.conv1.padding, self.bn1.state(), self.compute_dtype,
+                                       pool=(self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding),
+                                       mean=self._in_mean, inv_std=self._in_inv_std, pre_scale=self.input_scale)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        x = self.layer4(x)
+        return x
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        x = self.features(images)
+        x = self.avgpool(x)
+        return self.fc(x)
+
+
+_CFG = {
+    "resnet18": (BasicBlock, [2, 2, 2, 2]),
+    "resnet34": (BasicBlock, [3, 4, 6, 3]),
+    "resnet50": (Bottleneck, [3, 4, 6, 3]),
+    "resnet101": (Bottleneck, [3, 4, 23, 3]),
+    "resnet152": (Bottleneck, [3, 8, 36, 3]),
+}
+
+
+def _make(name):
+    def ctor(pretrained: bool = False, **kw) -> ResNet:
+        block, layers = _CFG[name]
+        model = ResNet(block, layers, **kw)
+        if pretrained:
+            from . import load_pretrained
+            load_pretrained(model, name)
+        return model
+    ctor.__name__ = name
+    ctor.__doc__ = f"{name} on the fused NHWC ops (torchvision-compatible state_dict)."
+    return ctor
+
+
+resnet18 = _make("resnet18")
+resnet34 = _make("resnet34")
+resnet50 = _make("resnet50")
+resnet101 = _make("resnet101")
+resnet152 = _make("resnet152")

@@ -1,0 +1,191 @@
+"""Layer modules over the NHWC device ops.
+
+Parameter / buffer names and logical shapes match ``torch.nn`` (and therefore
+torchvision checkpoints): ``Conv2d.weight`` is logically ``[K, C, R, S]`` but is
+kept in channels-last memory (physically KRSC, the GEMM B-operand layout);
+``BatchNorm2d`` carries ``weight, bias, running_mean, running_var,
+num_batches_tracked``.  Activations flowing between these modules are physically
+``[N, H, W, C]``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as tnn
+
+from .. import ops
+from ..ops import conv as _conv
+from ..ops.norm import BNState
+
+
+class Conv2d(tnn.Module):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, bias: bool = True):
+        super().__init__()
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        self.stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.weight = tnn.Parameter(_conv.make_weight(out_channels, in_channels, ks[0], ks[1]))
+        self.bias = tnn.Parameter(torch.empty(out_channels)) if bias else None
+        self._cache = _conv.WeightCache()
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        tnn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            tnn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache)
+
+    def extra_repr(self) -> str:
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, bias={self.bias is not None}, layout=NHWC")
+
+
+class BatchNorm2d(tnn.Module):
+    """BatchNorm over the channel (last) dimension of an NHWC tensor."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: Optional[float] = 0.1, affine: bool = True,
+                 track_running_stats: bool = True, process_group=None, sync: bool = False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.affine, self.track_running_stats = affine, track_running_stats
+        self.process_group, self.sync = process_group, sync
+        if affine:
+            self.weight = tnn.Parameter(torch.ones(num_features))
+            self.bias = tnn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        if track_running_stats:
+            self.register_buffer("running_mean", torch.zeros(num_features))
+            self.register_buffer("running_var", torch.ones(num_features))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        else:
+            self.register_buffer("running_mean", None)
+            self.register_buffer("running_var", None)
+            self.register_buffer("num_batches_tracked", None)
+
+    def state(self) -> BNState:
+        group = None
+        if self.sync and self.training:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+                group = self.process_group if self.process_group is not None else dist.group.WORLD
+        return BNState(self.eps, self.momentum, self.training, self.running_mean, self.running_var,
+                       self.num_batches_tracked, group)
+
+    def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+        return ops.batch_norm_act(x, self.weight, self.bias, residual, relu, self.state())
+
+    def extra_repr(self) -> str:
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, sync={self.sync}, layout=NHWC"
+
+
+class SyncBatchNorm(BatchNorm2d):
+    """BatchNorm2d whose batch statistics are all-reduced over ``process_group``."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
+                 process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats, process_group, sync=True)
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module: tnn.Module, process_group=None) -> tnn.Module:
+        """Switch every BatchNorm2d of this package inside ``module`` to cross-rank statistics (in place)."""
+        for m in module.modules():
+            if isinstance(m, BatchNorm2d):
+                m.sync = True
+                m.process_group = process_group
+        return module
+
+
+class ConvBnAct(tnn.Module):
+    """Functional fusion helper: runs ``conv`` + ``bn`` (+ residual) (+ ReLU) as one op while the two
+    sub-modules keep owning their parameters (so names stay ``conv1.weight`` / ``bn1.weight``)."""
+
+    @staticmethod
+    def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
+            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if conv.bias is not None:
+            return bn(conv(x), residual, relu)
+        return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
+                               bn.state(), conv._cache)
+
+
+class ReLU(tnn.Module):
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        return ops.relu(x)
+
+
+class MaxPool2d(tnn.Module):
+    def __init__(self, kernel_size: int, stride: Optional[int] = None, padding: int = 0):
+        super().__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride or kernel_size, padding
+
+    def forward(self, x):
+        return ops.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+
+class GlobalAvgPool2d(tnn.Module):
+    """AdaptiveAvgPool2d((1,1)) + flatten: [N,H,W,C] -> [N,C]."""
+
+    def forward(self, x):
+        return ops.global_avg_pool(x)
+
+
+class Dropout(tnn.Module):
+    def __init__(self, p: float = 0.5):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training)
+
+
+class Dropout2d(Dropout):
+    def forward(self, x):
+        return ops.dropout2d(x, self.p, self.training)
+
+
+class Linear(tnn.Linear):
+    """Plain library GEMM (hipBLASLt through torch); computes in the activation dtype."""
+
+    def forward(self, x):
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
+        b = self.bias
+        if b is not None and b.dtype != x.dtype:
+            b = b.to(x.dtype)
+        return tnn.functional.linear(x, w, b)
+
+
+class CrossEntropyLoss(tnn.Module):
+    """Softmax cross-entropy (mean). Pass ``metrics`` (4 floats on the logits' device) to also accumulate
+    {loss_sum, correct@1, correct@5, rows} on the device."""
+
+    def __init__(self, reduction: str = "mean"):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, logits, target, metrics: Optional[torch.Tensor] = None):
+        return ops.cross_entropy(logits, target, metrics, self.reduction)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """NCHW -> physically NHWC tensor of shape [N,H,W,C]."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+__all__ = ["Conv2d", "BatchNorm2d", "SyncBatchNorm", "ConvBnAct", "ReLU", "MaxPool2d", "GlobalAvgPool2d", "Dropout",
+           "Dropout2d", "Linear", "CrossEntropyLoss", "to_nhwc", "to_nchw"]

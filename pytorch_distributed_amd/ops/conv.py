@@ -1,0 +1,249 @@
+"""Convolution on NHWC tensors: MFMA implicit-GEMM kernels on the GPU, a plain
+PyTorch composition on the CPU.
+
+Tensors are physically ``[N, H, W, C]`` (channels innermost).  Weights are
+``nn.Parameter`` s of logical shape ``[K, C, R, S]`` stored in channels-last
+memory format, i.e. physically ``[K, R, S, C]`` ("KRSC"), which is both what the
+GEMM B operand wants (K contiguous) and what keeps ``state_dict()`` shape-compatible
+with torchvision checkpoints.
+
+Reference behaviour being reproduced: the torchvision ResNet convolutions that
+run under ``model(images)`` / ``loss.backward()`` in
+/root/reference/2.distributed.py:213,231 (cuDNN there).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_PARAM_GENERATION = 0  # bumped by our optimizers, which update weights behind autograd's back
+
+
+def bump_param_generation() -> None:
+    global _PARAM_GENERATION
+    _PARAM_GENERATION += 1
+
+
+def param_generation() -> int:
+    return _PARAM_GENERATION
+
+
+def out_size(i: int, k: int, s: int, p: int) -> int:
+    return (i + 2 * p - k) // s + 1
+
+
+def krsc(weight: torch.Tensor) -> torch.Tensor:
+    """Physical [K,R,S,C] view of a logical [K,C,R,S] channels-last weight (copies if needed)."""
+    w = weight.permute(0, 2, 3, 1)
+    return w if w.is_contiguous() else w.contiguous()
+
+
+def make_weight(k: int, c: int, r: int, s: int, device=None, dtype=torch.float32) -> torch.Tensor:
+    """Logical [K,C,R,S] tensor whose memory is KRSC."""
+    return torch.empty(k, r, s, c, device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+# --------------------------------------------------------------------------- raw GPU launches
+def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pad: Tuple[int, int],
+              res: Optional[torch.Tensor] = None, relu: bool = False, stats: bool = False, cfg: int = 0,
+              geom: Optional[tuple] = None):
+    """y = conv(x, w) [+ res] [relu]; optionally also per-tile column sums for BatchNorm.
+
+    ``geom`` overrides the gather geometry ``(N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S)`` for inputs
+    that are not plain NHWC (the padded 4-channel stem image).
+    """
+    l = _lib.lib()
+    K = w_krsc.shape[0]
+    if geom is None:
+        N, Hi, Wi, Ci = x.shape
+        R, S = w_krsc.shape[1], w_krsc.shape[2]
+        Ho, Wo = out_size(Hi, R, stride[0], pad[0]), out_size(Wi, S, stride[1], pad[1])
+        sn, sh, sw = Hi * Wi * Ci, Wi * Ci, Ci
+    else:
+        N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
+    M = N * Ho * Wo
+    y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
+    psum = psq = None
+    if stats:
+        bm = l.pda_conv_igemm_bm(M, K, cfg)
+        tiles_m = (M + bm - 1) // bm
+        part = torch.empty((2, tiles_m, K), device=x.device, dtype=torch.float32)
+        psum, psq = part[0], part[1]
+    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res),
+                          _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
+                          stride[0], stride[1], pad[0], pad[1], int(relu), cfg, _lib.stream())
+    if rc < 0:
+        return None  # shape not covered by the MFMA kernels
+    _lib.check(rc, "pda_conv_igemm(fprop)")
+    return (y, psum, psq) if stats else y
+
+
+def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], stride, pad,
+              res: Optional[torch.Tensor] = None, cfg: int = 0):
+    """dx[N,Hi,Wi,C] from dy[N,Ho,Wo,K]; w_crsk is the [C,R,S,K] transposed weight."""
+    l = _lib.lib()
+    N, Ho, Wo, K = dy.shape
+    C, R, S = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[2]
+    Hi, Wi = in_hw
+    dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
+    rc = l.pda_conv_igemm(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res), 0, 0,
+                          N, Ho, Wo, K, Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1],
+                          pad[0], pad[1], 0, cfg, _lib.stream())
+    if rc < 0:
+        return None
+    _lib.check(rc, "pda_conv_igemm(dgrad)")
+    return dx
+
+
+def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cfg: int = 0, nsplit: int = 0,
+              geom: Optional[tuple] = None, out: Optional[torch.Tensor] = None):
+    """fp32 dW in KRSC layout, shape [K,R,S,C] (accumulates into ``out`` when given)."""
+    l = _lib.lib()
+    K = dy.shape[-1]
+    if geom is None:
+        N, Hi, Wi, Ci = x.shape
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        sn, sh, sw = Hi * Wi * Ci, Wi * Ci, Ci
+    else:
+        N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
+    dw = out if out is not None else torch.zeros((K, R, S, Ci), device=dy.device, dtype=torch.float32)
+    rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
+                          Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit, _lib.stream())
+    if rc < 0:
+        return None
+    _lib.check(rc, "pda_conv_wgrad")
+    return dw
+
+
+def krsc_to_crsk(w_krsc: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    l = _lib.lib()
+    K, R, S, C = w_krsc.shape
+    out = torch.empty((C, R, S, K), device=w_krsc.device, dtype=dtype)
+    _lib.check(l.pda_krsc_to_crsk(_lib.dt(w_krsc), _lib.dt(dtype), w_krsc.data_ptr(), out.data_ptr(), K, R * S, C,
+                                  _lib.stream()), "pda_krsc_to_crsk")
+    return out
+
+
+def direct_conv(mode: int, a: torch.Tensor, b: torch.Tensor, bias, out: torch.Tensor, dims, stride, pad) -> None:
+    l = _lib.lib()
+    N, Hi, Wi, Ci, Ho, Wo, Co, R, S = dims
+    _lib.check(l.pda_direct_conv(_lib.dt(a), mode, a.data_ptr(), b.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                 N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride[0], stride[1], pad[0], pad[1],
+                                 _lib.stream()), "pda_direct_conv")
+
+
+# --------------------------------------------------------------------------- weight caches
+class WeightCache:
+    """Low-precision KRSC copy and CRSK transpose of one fp32 master weight, refreshed
+    only when the parameter has changed (torch version counter or our optimizer's
+    generation counter)."""
+
+    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp")
+
+    def __init__(self):
+        self.pinned_lp = None  # (dtype, tensor, torch version) kept current by the optimizer kernel (amp O2)
+        self.key_lp = None
+        self.lp = None
+        self.key_t = None
+        self.t = None
+
+    @staticmethod
+    def _key(weight: torch.Tensor, dtype) -> tuple:
+        return (weight.data_ptr(), weight._version, _PARAM_GENERATION, dtype)
+
+    def low_precision(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        w = krsc(weight.detach())
+        if w.dtype == dtype:
+            return w
+        if self.pinned_lp is not None and self.pinned_lp[0] == dtype:
+            if self.pinned_lp[2] != weight._version:  # changed through torch (load_state_dict, init): re-sync
+                self.pinned_lp[1].copy_(w)
+                self.pinned_lp = (dtype, self.pinned_lp[1], weight._version)
+            return self.pinned_lp[1]
+        key = self._key(weight, dtype)
+        if self.key_lp != key:
+            self.lp = w.to(dtype)
+            self.key_lp = key
+        return self.lp
+
+    def transposed(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        key = self._key(weight, dtype)
+        if self.key_t != key:
+            self.t = krsc_to_crsk(krsc(weight.detach()), dtype)
+            self.key_t = key
+        return self.t
+
+
+# --------------------------------------------------------------------------- autograd op
+class _Conv2dFn(torch.autograd.Function):
+    """Plain convolution (optional bias) on the GPU kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, cache: WeightCache):
+        x = x.contiguous()
+        dtype = x.dtype
+        K, C, R, S = weight.shape
+        w_lp = cache.low_precision(weight, dtype)
+        N, Hi, Wi, _ = x.shape
+        Ho, Wo = out_size(Hi, R, stride[0], pad[0]), out_size(Wi, S, stride[1], pad[1])
+        y = fprop_gpu(x, w_lp, stride, pad)
+        ctx.used_igemm = y is not None
+        if y is None:
+            y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=dtype)
+            direct_conv(0, x, w_lp, bias.float() if bias is not None else None, y,
+                        (N, Hi, Wi, C, Ho, Wo, K, R, S), stride, pad)
+        elif bias is not None:
+            l = _lib.lib()
+            _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), K,
+                                      0, _lib.stream()), "pda_bias_add")
+        ctx.save_for_backward(x, weight)
+        ctx.w_lp = w_lp
+        ctx.cfg = (stride, pad, cache, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, cache, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        K, C, R, S = weight.shape
+        N, Hi, Wi, _ = x.shape
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        dims = (N, Hi, Wi, C, Ho, Wo, K, R, S)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (Hi, Wi), stride, pad) if ctx.used_igemm else None
+            if dx is None:
+                dx = torch.empty_like(x)
+                direct_conv(1, dy, ctx.w_lp, None, dx, dims, stride, pad)
+        if ctx.needs_input_grad[1]:
+            dwk = wgrad_gpu(dy, x, R, S, stride, pad) if ctx.used_igemm else None
+            if dwk is None:
+                dwk = torch.zeros((K, R, S, C), device=dy.device, dtype=torch.float32)
+                direct_conv(2, dy, x, None, dwk, dims, stride, pad)
+            dw = dwk.permute(0, 3, 1, 2).to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            l = _lib.lib()
+            db = torch.empty(K, device=dy.device, dtype=torch.float32)
+            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), N * Ho * Wo, K, _lib.stream()),
+                       "pda_colsum")
+        return dx, dw, db, None, None, None
+
+
+def conv2d_ref(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad) -> torch.Tensor:
+    """CPU / reference path: NHWC in, NHWC out, stock PyTorch math."""
+    y = F.conv2d(x.permute(0, 3, 1, 2), weight.to(x.dtype), None if bias is None else bias.to(x.dtype),
+                 stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=(0, 0),
+           cache: Optional[WeightCache] = None) -> torch.Tensor:
+    """NHWC convolution. ``weight`` is logical [K,C,R,S]."""
+    if not x.is_cuda:
+        return conv2d_ref(x, weight, bias, stride, pad)
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())

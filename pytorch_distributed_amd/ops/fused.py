@@ -1,0 +1,204 @@
+"""Fused ResNet building blocks.
+
+``conv_bn_act``  : conv (implicit GEMM, BatchNorm statistics accumulated in the GEMM
+                   epilogue) -> finalize -> one pass doing normalise + residual add + ReLU.
+                   Backward: BN reduce -> BN apply (+ReLU mask, + residual gradient) ->
+                   dgrad / wgrad on MFMA.
+``stem_conv_bn_relu_pool`` : the 7x7/s2 stem on a 3-channel NCHW image: the loader's
+                   layout change + normalisation + cast + zero border run as one kernel,
+                   the conv runs as an implicit GEMM over (row tap x 8 contiguous pixels x 4
+                   padded channels), followed by BN+ReLU and the 3x3/s2 max-pool.
+
+One autograd node per conv+BN+activation keeps the Python/autograd overhead of a
+ResNet-50 step at ~55 nodes instead of ~175 (SURVEY K1/K6/K8/K9 fusion plan;
+reference: the torchvision Bottleneck/BasicBlock forward under
+/root/reference/2.distributed.py:213).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, conv as C, norm as Nm, pool as P
+
+
+class _ConvBnActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
+                cache: C.WeightCache):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        dtype = x.dtype
+        K, Cin, R, S = weight.shape
+        w_lp = cache.low_precision(weight, dtype)
+        train_stats = st.training or st.running_mean is None
+        r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats)
+        if r is None:
+            raise RuntimeError(
+                f"conv_bn_act: shape not supported by the MFMA kernels (Cin={Cin}, dtype={dtype}); "
+                "use nn.Conv2d + nn.BatchNorm2d modules for this layer")
+        if train_stats:
+            y, psum, psq = r
+            M = y.numel() // K
+            mean, invstd, scale, shift, count = Nm.finalize(psum, psq, float(M), gamma, beta, st)
+        else:
+            y = r
+            scale, shift = Nm.eval_coeffs(gamma, beta, st)
+            mean = invstd = None
+            count = float(y.numel() // K)
+        out = Nm.apply(y, scale, shift, residual, relu)
+        ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
+        mask_src = out if (relu and (residual is not None or not train_stats)) else None
+        ctx.save_for_backward(x, weight, y if train_stats else None, mask_src, mean, invstd, scale, shift, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, y, mask_src, mean, invstd, scale, shift, gamma = ctx.saved_tensors
+        stride, pad, relu, has_res, count, group, cache, train_stats = ctx.cfg
+        dout = dout.contiguous()
+        K, Cin, R, S = weight.shape
+        if train_stats:
+            dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
+                                           has_res, group)
+        else:
+            g = dout if not relu else dout * (mask_src > 0).to(dout.dtype)
+            dy = (g.float() * scale).to(dout.dtype)
+            dres = g if has_res else None
+            dg = db = None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad)
+            if dx is None:
+                dx = torch.empty_like(x)
+                C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
+                              (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
+        if ctx.needs_input_grad[1]:
+            dwk = C.wgrad_gpu(dy, x, R, S, stride, pad)
+            if dwk is None:
+                raise RuntimeError("conv_bn_act: wgrad shape not supported")
+            dw = dwk.permute(0, 3, 1, 2)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
+            dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
+        return dx, dw, dg, db, dres, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
+                cache: Optional[C.WeightCache] = None):
+    """NHWC fused conv + BatchNorm (+residual) (+ReLU)."""
+    if not x.is_cuda:
+        y = C.conv2d_ref(x, weight, None, stride, pad)
+        return Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
+    return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
+                              cache or C.WeightCache())
+
+
+# ------------------------------------------------------------------------------------ stem
+def _stem_geometry(N, H, W, R, S, stride, pad):
+    """Geometry of the stem conv as an implicit GEMM over a zero-bordered 4-channel image.
+
+    The bordered image is [N][Hp][Wp][4]; one GEMM K-step = one filter row r = 8
+    consecutive pixels x 4 channels = 32 contiguous values, so the gathered "tensor"
+    has Ci=32, R taps, S=1 and a pixel stride of stride*4 elements.
+    """
+    assert S <= 8 and stride[1] * 4 % 8 == 0, "stem kernel wants filter width <= 8 and an even stride"
+    Ho, Wo = C.out_size(H, R, stride[0], pad[0]), C.out_size(W, S, stride[1], pad[1])
+    Hp = H + 2 * pad[0]
+    Wp = max(W + 2 * pad[1], (Wo - 1) * stride[1] + 8)
+    Wp += Wp % 2
+    geom = (N, Hp, 1 << 30, 32, Hp * Wp * 4, Wp * 4, stride[1] * 4, Ho, Wo, R, 1)
+    return Hp, Wp, Ho, Wo, geom
+
+
+def stem_weight(weight: torch.Tensor, dtype) -> torch.Tensor:
+    """[K,3,R,S] master weight -> [K][R][8][4] (zero padded) GEMM B operand."""
+    K, Cin, R, S = weight.shape
+    w = torch.zeros((K, R, 8, 4), device=weight.device, dtype=dtype)
+    w[:, :, :S, :Cin] = weight.detach().permute(0, 2, 3, 1).to(dtype)
+    return w
+
+
+def input_to_nhwc(images: torch.Tensor, dtype, cp: int, pad_hw=(0, 0), wp: Optional[int] = None, mean=None,
+                  inv_std=None, pre_scale: float = 1.0) -> torch.Tensor:
+    """NCHW (uint8/fp32/fp16) -> zero-bordered NHWC[cp] in the compute dtype, normalised."""
+    l = _lib.lib()
+    images = images.contiguous()
+    N, Cc, H, W = images.shape
+    Hp = H + 2 * pad_hw[0]
+    Wp = wp if wp is not None else W + 2 * pad_hw[1]
+    out = torch.empty((N, Hp, Wp, cp), device=images.device, dtype=dtype)
+    _lib.check(l.pda_nchw_to_nhwc(_lib.dt(images), _lib.dt(dtype), images.data_ptr(), out.data_ptr(), N, Cc, H, W,
+                                  cp, Hp, Wp, pad_hw[0], pad_hw[1], _lib.ptr(mean), _lib.ptr(inv_std),
+                                  float(pre_scale), _lib.stream()), "pda_nchw_to_nhwc")
+    return out
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, weight, gamma, beta, stride, pad, st: Nm.BNState, dtype, pool, mean, inv_std,
+                pre_scale):
+        N, Cin, H, W = images.shape
+        K, _, R, S = weight.shape
+        Hp, Wp, Ho, Wo, geom = _stem_geometry(N, H, W, R, S, stride, pad)
+        xp = input_to_nhwc(images, dtype, 4, (pad[0], pad[1]), Wp, mean, inv_std, pre_scale)
+        w_st = stem_weight(weight, dtype)
+        train_stats = st.training or st.running_mean is None
+        r = C.fprop_gpu(xp, w_st.view(K, R, 1, 32), (stride[0], 1), (0, 0), stats=train_stats, geom=geom)
+        if r is None:
+            raise RuntimeError("stem conv: unsupported configuration")
+        if train_stats:
+            y, psum, psq = r
+            mean_, invstd, scale, shift, count = Nm.finalize(psum, psq, float(y.numel() // K), gamma, beta, st)
+        else:
+            y = r
+            scale, shift = Nm.eval_coeffs(gamma, beta, st)
+            mean_ = invstd = None
+            count = float(y.numel() // K)
+        act = Nm.apply(y, scale, shift, None, True)
+        if pool is not None:
+            out, idx = P.maxpool_fwd_gpu(act, *pool)
+        else:
+            out, idx = act, None
+        ctx.cfg = (stride, pad, geom, count, st.group, pool, act.shape, train_stats, weight.shape)
+        ctx.save_for_backward(xp, y if train_stats else None, idx, mean_, invstd, scale, shift, gamma,
+                              act if not train_stats else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xp, y, idx, mean_, invstd, scale, shift, gamma, act = ctx.saved_tensors
+        stride, pad, geom, count, group, pool, act_shape, train_stats, wshape = ctx.cfg
+        dout = dout.contiguous()
+        K, Cin, R, S = wshape
+        dact = P.maxpool_bwd_gpu(dout, idx, act_shape, *pool) if pool is not None else dout
+        if train_stats:
+            dy, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group)
+        else:
+            dy = ((dact * (act > 0).to(dact.dtype)).float() * scale).to(dact.dtype)
+            dg = db = None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dwk = C.wgrad_gpu(dy, xp, R, 1, (stride[0], 1), (0, 0), geom=geom)  # [K][R][1][32]
+            if dwk is None:
+                raise RuntimeError("stem wgrad: unsupported configuration")
+            dw = dwk.view(K, R, 8, 4)[:, :, :S, :Cin].permute(0, 3, 1, 2)
+        return None, dw, dg, db, None, None, None, None, None, None, None, None
+
+
+def stem_conv_bn_relu_pool(images, weight, gamma, beta, stride, pad, st: Nm.BNState, dtype, pool=(3, 2, 1),
+                           mean=None, inv_std=None, pre_scale: float = 1.0):
+    """images NCHW -> NHWC feature map after conv+BN+ReLU(+maxpool)."""
+    if not images.is_cuda:
+        x = images.float() * pre_scale
+        if mean is not None:
+            x = (x - mean.view(1, -1, 1, 1)) * inv_std.view(1, -1, 1, 1)
+        x = x.to(dtype).permute(0, 2, 3, 1)
+        y = C.conv2d_ref(x, weight, None, stride, pad)
+        a = Nm.batch_norm_act_ref(y, gamma, beta, None, True, st)
+        return P.max_pool2d(a, *pool) if pool is not None else a
+    return _StemFn.apply(images, weight, gamma, beta, tuple(stride), tuple(pad), st, dtype, pool, mean, inv_std,
+                         pre_scale)

@@ -1,0 +1,225 @@
+"""BatchNorm building blocks (NHWC, viewed as [M, C]) and the stand-alone
+BatchNorm(+ReLU, +residual) autograd op.
+
+GPU path = the kernels of ``csrc/kernels/bn.hip``; CPU path = ``F.batch_norm``.
+``group`` enables SyncBatchNorm: per-channel (sum, sum of squares, count) are
+all-reduced between the statistics pass and the normalisation pass, and
+(sum dy, sum dy*xhat) in backward - two small all-reduces per layer per direction.
+Reference: torchvision BatchNorm2d under /root/reference/2.distributed.py:213;
+SyncBN itself is absent upstream and required by the port's north-star config.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class BNState:
+    """Mutable, non-tensor configuration handed to the autograd ops."""
+
+    __slots__ = ("eps", "momentum", "training", "running_mean", "running_var", "num_batches_tracked", "group")
+
+    def __init__(self, eps, momentum, training, running_mean, running_var, num_batches_tracked, group=None):
+        self.eps = eps
+        self.momentum = momentum
+        self.training = training
+        self.running_mean = running_mean
+        self.running_var = running_var
+        self.num_batches_tracked = num_batches_tracked
+        self.group = group
+
+
+def _world(group) -> int:
+    if group is None:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def stats_partials(y2d: torch.Tensor):
+    """Per-row-block column sums of y[M][C] -> (psum, psq) each [nparts][C] fp32."""
+    l = _lib.lib()
+    M, C = y2d.shape
+    n = l.pda_bn_num_partials(M)
+    part = torch.empty((2, n, C), device=y2d.device, dtype=torch.float32)
+    _lib.check(l.pda_bn_stats_partial(_lib.dt(y2d), y2d.data_ptr(), M, C, part[0].data_ptr(), part[1].data_ptr(),
+                                      _lib.stream()), "pda_bn_stats_partial")
+    return part[0], part[1]
+
+
+def finalize(psum, psq, count: float, gamma, beta, st: BNState):
+    """partials -> (mean, invstd, scale, shift); updates running stats in place."""
+    l = _lib.lib()
+    C = psum.shape[-1]
+    nparts = psum.shape[0]
+    dev = psum.device
+    world = _world(st.group)
+    if world > 1:
+        import torch.distributed as dist
+        sums = torch.empty((2 * C,), device=dev, dtype=torch.float32)
+        _lib.check(l.pda_bn_reduce_partials(psum.data_ptr(), psq.data_ptr(), nparts, C, sums.data_ptr(),
+                                            _lib.stream()), "pda_bn_reduce_partials")
+        dist.all_reduce(sums, group=st.group)
+        # every rank of a data-parallel job runs the same per-rank batch, so the global
+        # element count is known on the host and no device->host read is needed
+        count = count * world
+        psum, psq, nparts = sums[:C], sums[C:], 1
+    out = torch.empty((4, C), device=dev, dtype=torch.float32)
+    rm = st.running_mean if (st.training and st.running_mean is not None) else None
+    rv = st.running_var if (st.training and st.running_var is not None) else None
+    mom = st.momentum
+    if st.num_batches_tracked is not None and st.training:
+        st.num_batches_tracked += 1
+        if mom is None:  # cumulative moving average, as torch does for momentum=None
+            mom = 1.0 / float(st.num_batches_tracked.item())
+    _lib.check(l.pda_bn_finalize(psum.data_ptr(), psq.data_ptr(), nparts, C, float(count), float(st.eps),
+                                 float(mom if mom is not None else 0.1), _lib.ptr(gamma), _lib.ptr(beta),
+                                 _lib.ptr(rm), _lib.ptr(rv), out[0].data_ptr(), out[1].data_ptr(),
+                                 out[2].data_ptr(), out[3].data_ptr(), _lib.stream()), "pda_bn_finalize")
+    return out[0], out[1], out[2], out[3], count
+
+
+def eval_coeffs(gamma, beta, st: BNState):
+    l = _lib.lib()
+    C = st.running_mean.numel()
+    out = torch.empty((2, C), device=st.running_mean.device, dtype=torch.float32)
+    _lib.check(l.pda_bn_eval_coeffs(C, float(st.eps), _lib.ptr(gamma), _lib.ptr(beta), st.running_mean.data_ptr(),
+                                    st.running_var.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), _lib.stream()),
+               "pda_bn_eval_coeffs")
+    return out[0], out[1]
+
+
+def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    l = _lib.lib()
+    C = y.shape[-1]
+    M = y.numel() // C
+    out = torch.empty_like(y)
+    _lib.check(l.pda_bn_apply(_lib.dt(y), y.data_ptr(), _lib.ptr(res), out.data_ptr(), scale.data_ptr(),
+                              shift.data_ptr(), M, C, int(relu), _lib.stream()), "pda_bn_apply")
+    return out
+
+
+def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu: bool, want_dres: bool,
+             group=None):
+    """-> dy, dres (or None), dgamma, dbeta."""
+    l = _lib.lib()
+    C = y.shape[-1]
+    M = y.numel() // C
+    dev = y.device
+    n = l.pda_bn_num_partials(M)
+    part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
+    _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
+                                   invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C, int(relu),
+                                   part[0].data_ptr(), part[1].data_ptr(), _lib.stream()), "pda_bn_bwd_reduce")
+    dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
+    _lib.check(l.pda_reduce2_partials(part[0].data_ptr(), part[1].data_ptr(), n, C, dgb[0].data_ptr(),
+                                      dgb[1].data_ptr(), _lib.stream()), "pda_reduce2_partials")
+    dg_tot = dgb
+    if _world(group) > 1:
+        import torch.distributed as dist
+        dg_tot = dgb.clone()
+        dist.all_reduce(dg_tot, group=group)  # dx needs the global sums; the parameter grads stay local
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
+                                  invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma),
+                                  dg_tot[0].data_ptr(), dg_tot[1].data_ptr(), M, C, float(count), int(relu),
+                                  dy.data_ptr(), _lib.ptr(dres), _lib.stream()), "pda_bn_bwd_apply")
+    return dy, dres, dgb[0], dgb[1]
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """out = relu(bn(y) + residual) on the GPU kernels (stand-alone, not fused with a conv)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, relu: bool, st: BNState):
+        y = y.contiguous()
+        C = y.shape[-1]
+        M = y.numel() // C
+        if residual is not None:
+            residual = residual.contiguous()
+        if st.training or st.running_mean is None:
+            psum, psq = stats_partials(y.view(M, C))
+            mean, invstd, scale, shift, count = finalize(psum, psq, float(M), gamma, beta, st)
+        else:
+            scale, shift = eval_coeffs(gamma, beta, st)
+            mean = invstd = None
+            count = float(M)
+        out = apply(y, scale, shift, residual, relu)
+        ctx.relu, ctx.has_res, ctx.count, ctx.group = relu, residual is not None, count, st.group
+        ctx.train = mean is not None
+        if ctx.train:
+            ctx.save_for_backward(y, out if (relu and residual is not None) else None, mean, invstd, scale, shift, gamma)
+        else:
+            ctx.save_for_backward(out if relu else None, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        if not ctx.train:  # eval-mode BN is an affine map
+            out, scale = ctx.saved_tensors
+            g = dout if out is None else dout * (out > 0).to(dout.dtype)
+            return (g.float() * scale).to(dout.dtype), None, None, (g if ctx.has_res else None), None, None
+        y, out, mean, invstd, scale, shift, gamma = ctx.saved_tensors
+        dy, dres, dg, db = backward(dout, y, out, mean, invstd, scale, shift, gamma, ctx.count, ctx.relu,
+                                    ctx.has_res, ctx.group)
+        return (dy, dg.to(gamma.dtype) if gamma is not None else None,
+                db.to(gamma.dtype) if gamma is not None else None, dres, None, None)
+
+
+def batch_norm_act_ref(y, gamma, beta, residual, relu, st: BNState):
+    """CPU path; NHWC in/out."""
+    x = y.permute(0, 3, 1, 2) if y.dim() == 4 else y
+    use_batch = st.training or st.running_mean is None
+    if st.training and st.num_batches_tracked is not None:
+        st.num_batches_tracked += 1
+    mom = st.momentum
+    if mom is None:
+        mom = 1.0 / float(st.num_batches_tracked) if st.num_batches_tracked is not None and use_batch else 0.0
+    if use_batch and _world(st.group) > 1:
+        o = _sync_bn_ref(x, gamma, beta, st, mom)
+    else:
+        o = F.batch_norm(x.float(), st.running_mean, st.running_var, None if gamma is None else gamma.float(),
+                         None if beta is None else beta.float(), use_batch, mom, st.eps).to(y.dtype)
+    if y.dim() == 4:
+        o = o.permute(0, 2, 3, 1)
+    if residual is not None:
+        o = o + residual
+    if relu:
+        o = torch.relu(o)
+    return o.contiguous()
+
+
+def _sync_bn_ref(x, gamma, beta, st: BNState, mom):
+    """SyncBN on the CPU/gloo path: differentiable all-reduce of (sum, sumsq, count)."""
+    import torch.distributed as dist
+    from torch.distributed.nn.functional import all_reduce as ar
+    xf = x.float()
+    dims = [0] + list(range(2, xf.dim()))
+    C = xf.shape[1]
+    n_local = xf.numel() // C
+    packed = torch.cat([xf.sum(dims), (xf * xf).sum(dims), torch.tensor([float(n_local)])])
+    packed = ar(packed, group=st.group)
+    cnt = packed[2 * C]
+    mean = packed[:C] / cnt
+    var = (packed[C:2 * C] / cnt - mean * mean).clamp_min(0.0)
+    if st.training and st.running_mean is not None:
+        with torch.no_grad():
+            st.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
+            st.running_var.mul_(1 - mom).add_(var.detach() * (cnt / (cnt - 1).clamp_min(1.0)) * mom)
+    shape = [1, C] + [1] * (xf.dim() - 2)
+    o = (xf - mean.view(shape)) * torch.rsqrt(var.view(shape) + st.eps)
+    if gamma is not None:
+        o = o * gamma.float().view(shape) + beta.float().view(shape)
+    return o.to(x.dtype)
+
+
+def batch_norm_act(y, gamma, beta, residual, relu: bool, st: BNState):
+    if not y.is_cuda:
+        return batch_norm_act_ref(y, gamma, beta, residual, relu, st)
+    return _BatchNormActFn.apply(y, gamma, beta, residual, relu, st)

@@ -1,0 +1,108 @@
+"""Momentum SGD as one multi-tensor HIP launch per parameter group.
+
+Same update rule and ``state_dict`` layout as ``torch.optim.SGD`` (per-parameter
+``momentum_buffer``; first step initialises the buffer with the gradient), i.e. the
+optimizer every reference script builds at /root/reference/2.distributed.py:120
+(lr 0.1, momentum 0.9, weight_decay 1e-4).  On top of that the kernel
+
+* divides the gradients by the mixed-precision loss scale it reads from device
+  memory (so no separate unscale pass is needed),
+* skips the whole update when the overflow flag written by the gradient check is
+  set (no host round trip: the decision is taken on the device),
+* optionally writes the half-precision model copy of every fp32 master weight in
+  the same pass (apex "O2" master weights).
+
+Hyper-parameters live in a small device tensor per group so that changing the
+learning rate (``adjust_learning_rate``) does not need a new kernel argument and
+stays valid under hipGraph replay.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch.optim import Optimizer
+
+from ..ops import multi_tensor as mt
+from ..ops.conv import bump_param_generation
+
+
+class FusedSGD(Optimizer):
+    def __init__(self, params, lr: float = 0.1, momentum: float = 0.0, dampening: float = 0.0,
+                 weight_decay: float = 0.0, nesterov: bool = False):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov)
+        super().__init__(params, defaults)
+        self._hp: Dict[int, torch.Tensor] = {}
+        self._hp_host: Dict[int, tuple] = {}
+        self._lists: Dict[int, tuple] = {}
+        self._amp_scaler = None          # set by amp.initialize
+        self._model_copies: Dict[int, torch.Tensor] = {}  # id(param) -> half copy updated in-kernel
+
+    # -- mixed precision hooks -------------------------------------------------------------
+    def attach_scaler(self, scaler) -> None:
+        self._amp_scaler = scaler
+
+    def register_model_copy(self, param: torch.Tensor, copy: torch.Tensor) -> None:
+        """Have ``step`` also write ``copy`` (same numel, fp16/bf16) = cast(param) in the update kernel."""
+        assert copy.numel() == param.numel()
+        self._model_copies[id(param)] = copy
+        self._lists.clear()
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _group_hp(self, gi: int, group, device) -> torch.Tensor:
+        host = (float(group["lr"]), float(group["momentum"]), float(group["dampening"]),
+                float(group["weight_decay"]), 1.0 if group["nesterov"] else 0.0)
+        if self._hp_host.get(gi) != host or gi not in self._hp or self._hp[gi].device != device:
+            t = torch.tensor(host, dtype=torch.float32)
+            if gi in self._hp and self._hp[gi].device == device:
+                self._hp[gi].copy_(t, non_blocking=True)
+            else:
+                self._hp[gi] = t.to(device)
+            self._hp_host[gi] = host
+        return self._hp[gi]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        scaler = self._amp_scaler
+        dev_scale = noop = None
+        if scaler is not None and scaler.enabled:
+            dev_scale = scaler.scale_tensor if scaler.grads_scaled else None
+            noop = scaler.overflow_flag
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            first = any("momentum_buffer" not in self.state[p] for p in ps) and group["momentum"] != 0
+            # partition by (grad dtype, has model copy): one launch each
+            buckets: Dict[tuple, List[torch.Tensor]] = {}
+            for p in ps:
+                mc = self._model_copies.get(id(p))
+                key = (p.grad.dtype, None if mc is None else mc.dtype, "momentum_buffer" in self.state[p])
+                buckets.setdefault(key, []).append(p)
+            for key, plist in buckets.items():
+                fresh = not key[2] and group["momentum"] != 0
+                for p in plist:
+                    if "momentum_buffer" not in self.state[p]:
+                        self.state[p]["momentum_buffer"] = torch.zeros_like(p, dtype=torch.float32)
+                ck = (gi, key, tuple(id(p) for p in plist), tuple(p.grad.data_ptr() for p in plist))
+                tl = self._lists.get(ck)
+                if tl is None:
+                    lists = [[p.grad for p in plist], list(plist), [self.state[p]["momentum_buffer"] for p in plist]]
+                    if key[1] is not None:
+                        lists.append([self._model_copies[id(p)] for p in plist])
+                    tl = mt.TensorLists(lists)
+                    if len(self._lists) > 64:
+                        self._lists.clear()
+                    self._lists[ck] = tl
+                mt.sgd(tl, self._group_hp(gi, group, plist[0].device), first_run=fresh, dev_scale=dev_scale,
+                       noop_flag=noop)
+        bump_param_generation()
+        if scaler is not None and scaler.enabled:
+            scaler.after_step()
+        return loss

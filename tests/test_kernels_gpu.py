@@ -1,0 +1,372 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op
+(run on the GPU box: `pytest -m gpu`)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pytorch_distributed_amd import ops, nn as pnn, models
+from pytorch_distributed_amd.ops import conv as C, norm as Nm, fused, pool as P, multi_tensor as mt, _lib
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-4, torch.float16: 2e-2, torch.bfloat16: 8e-2}
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+def _ref_conv(x, w, stride, pad):
+    # x NHWC, w logical KCRS -> NHWC, computed in fp32 on the rounded inputs
+    return F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, stride, pad).permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, K, R, stride, pad
+    (2, 8, 8, 64, 64, 3, 1, 1),
+    (2, 8, 8, 64, 128, 3, 2, 1),
+    (4, 14, 14, 128, 256, 1, 1, 0),
+    (2, 14, 14, 256, 512, 1, 2, 0),
+    (3, 7, 7, 512, 512, 3, 1, 1),
+    (2, 9, 11, 64, 96, 3, 1, 1),      # odd spatial size, K not a multiple of the tile
+    (1, 28, 28, 128, 128, 3, 2, 1),
+    (16, 4, 4, 256, 1024, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop_dgrad_wgrad(case, dtype):
+    N, H, W, Cin, K, R, s, p = case
+    torch.manual_seed(1)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    w = (torch.randn(K, R, R, Cin, device=DEV) / (R * R * Cin) ** 0.5).to(dtype).permute(0, 3, 1, 2)  # logical KCRS
+    xr = x.float().requires_grad_(True)
+    wr = w.float().contiguous().requires_grad_(True)
+    yr = _ref_conv(xr, wr, s, p)
+    y = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p))
+    assert y is not None
+    assert rel_err(y, yr) < TOL[dtype], "fprop"
+    dy = torch.randn_like(yr).to(dtype)
+    yr.backward(dy.float())
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    dx = C.dgrad_gpu(dy, wt, (H, W), (s, s), (p, p))
+    assert dx is not None
+    assert rel_err(dx, xr.grad) < TOL[dtype], "dgrad"
+    dw = C.wgrad_gpu(dy, x, R, R, (s, s), (p, p))
+    assert dw is not None
+    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], "wgrad"
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 9, 10, 11])
+def test_conv_tile_configs(cfg):
+    torch.manual_seed(2)
+    N, H, W, Cin, K = 3, 10, 10, 128, 192
+    x = torch.randn(N, H, W, Cin, device=DEV).half()
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 34).half().permute(0, 3, 1, 2)
+    yr = _ref_conv(x, w, 1, 1)
+    r = C.fprop_gpu(x, C.krsc(w), (1, 1), (1, 1), stats=True, cfg=cfg)
+    y, psum, psq = r
+    assert rel_err(y, yr) < 2e-2
+    yf = y.float().view(-1, K)
+    assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
+    assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+
+
+def test_conv_epilogue_residual_relu():
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 8, 64, device=DEV).half()
+    w = (torch.randn(64, 3, 3, 64, device=DEV) / 24).half().permute(0, 3, 1, 2)
+    res = torch.randn(2, 8, 8, 64, device=DEV).half()
+    y = C.fprop_gpu(x, C.krsc(w), (1, 1), (1, 1), res=res, relu=True)
+    yr = torch.relu(_ref_conv(x, w, 1, 1) + res.float())
+    assert rel_err(y, yr) < 2e-2
+
+
+def test_wgrad_tiles_and_splits():
+    torch.manual_seed(4)
+    N, H, W, Cin, K = 4, 12, 12, 128, 128
+    x = torch.randn(N, H, W, Cin, device=DEV).half()
+    dy = torch.randn(N, H, W, K, device=DEV).half()
+    wr = torch.zeros(K, Cin, 3, 3, device=DEV, requires_grad=True)
+    _ref_conv(x, wr, 1, 1).backward(dy.float())
+    for cfg in (1, 2):
+        for nsplit in (0, 1, 3):
+            dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), cfg=cfg, nsplit=nsplit)
+            assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-2, (cfg, nsplit)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_act_fwd_bwd(dtype, relu, use_res):
+    torch.manual_seed(5)
+    N, H, W, Cc = 4, 9, 9, 64
+    y = (torch.randn(N, H, W, Cc, device=DEV) * 2 + 0.5).to(dtype).requires_grad_(True)
+    res = torch.randn(N, H, W, Cc, device=DEV).to(dtype).requires_grad_(True) if use_res else None
+    bn = pnn.BatchNorm2d(Cc).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    rbn = torch.nn.BatchNorm2d(Cc).to(DEV)
+    rbn.load_state_dict(bn.state_dict())
+    out = bn(y, res, relu)
+    yr = y.detach().float().requires_grad_(True)
+    rr = res.detach().float().requires_grad_(True) if use_res else None
+    o = rbn(yr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    if use_res:
+        o = o + rr
+    if relu:
+        o = torch.relu(o)
+    assert rel_err(out, o) < TOL[dtype]
+    g = torch.randn_like(o)
+    out.backward(g.to(dtype))
+    o.backward(g)
+    assert rel_err(y.grad, yr.grad) < 3 * TOL[dtype]
+    assert rel_err(bn.weight.grad, rbn.weight.grad) < 3 * TOL[dtype]
+    assert rel_err(bn.bias.grad, rbn.bias.grad) < 3 * TOL[dtype]
+    if use_res:
+        assert rel_err(res.grad, rr.grad) < 3 * TOL[dtype]
+    assert rel_err(bn.running_mean, rbn.running_mean) < 1e-3
+    assert rel_err(bn.running_var, rbn.running_var) < 1e-3
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_batchnorm_eval():
+    torch.manual_seed(6)
+    bn = pnn.BatchNorm2d(128).to(DEV)
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2)
+    bn.eval()
+    x = torch.randn(2, 5, 5, 128, device=DEV).half()
+    out = bn(x, None, True)
+    ref = torch.relu(F.batch_norm(x.float().permute(0, 3, 1, 2), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                  False, 0.1, bn.eps)).permute(0, 2, 3, 1)
+    assert rel_err(out, ref) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape,k,s,p", [((2, 16, 16, 64), 3, 2, 1), ((3, 24, 24, 10), 2, 2, 0), ((2, 9, 9, 20), 2, 2, 0)])
+def test_maxpool(shape, k, s, p, dtype):
+    torch.manual_seed(7)
+    x = torch.randn(*shape, device=DEV).to(dtype).requires_grad_(True)
+    out = ops.max_pool2d(x, k, s, p)
+    xr = x.detach().float().requires_grad_(True)
+    o = F.max_pool2d(xr.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1)
+    assert rel_err(out, o) < 1e-6
+    g = torch.randn_like(o)
+    out.backward(g.to(dtype))
+    o.backward(g)
+    assert rel_err(x.grad, xr.grad) < TOL[dtype]
+
+
+def test_global_avg_pool():
+    x = torch.randn(4, 7, 7, 2048, device=DEV).half().requires_grad_(True)
+    out = ops.global_avg_pool(x)
+    assert rel_err(out, x.float().mean((1, 2))) < 2e-3
+    out.backward(torch.ones_like(out))
+    assert rel_err(x.grad, torch.full_like(x, 1 / 49.0)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_softmax_ce_and_metrics(dtype):
+    torch.manual_seed(8)
+    B, NC = 37, 1000
+    z = (torch.randn(B, NC, device=DEV) * 3).to(dtype).requires_grad_(True)
+    t = torch.randint(0, NC, (B,), device=DEV)
+    with torch.no_grad():
+        z[0, t[0]] = 50.0  # a certain hit
+    metrics = ops.new_metrics(DEV)
+    loss = ops.cross_entropy(z, t, metrics)
+    zr = z.detach().float().requires_grad_(True)
+    lr = F.cross_entropy(zr, t)
+    assert abs(loss.item() - lr.item()) < 1e-3 * max(1.0, abs(lr.item()))
+    (loss * 128.0).backward()
+    (lr * 128.0).backward()
+    assert rel_err(z.grad, zr.grad) < TOL[dtype]
+    top1 = (zr.argmax(1) == t).sum().item()
+    top5 = (zr.topk(5, 1).indices == t[:, None]).any(1).sum().item()
+    m = metrics.tolist()
+    assert abs(m[0] - lr.item() * B) < 1e-2 * B
+    assert m[1] == top1 and m[2] == top5 and m[3] == B
+
+
+def test_log_softmax():
+    z = torch.randn(9, 10, device=DEV, requires_grad=True)
+    out = ops.log_softmax(z)
+    zr = z.detach().clone().requires_grad_(True)
+    o = F.log_softmax(zr, 1)
+    assert rel_err(out, o) < 1e-5
+    g = torch.randn_like(o)
+    out.backward(g)
+    o.backward(g)
+    assert rel_err(z.grad, zr.grad) < 1e-4
+
+
+def test_multi_tensor_scale_flag_and_l2norm():
+    torch.manual_seed(9)
+    srcs = [torch.randn(n, device=DEV) for n in (5, 1000, 70001, 64)]
+    dsts = [torch.empty(n, device=DEV, dtype=torch.float16) for n in (5, 1000, 70001, 64)]
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    mt.scale(mt.TensorLists([srcs, dsts]), 0.5, noop_flag=flag)
+    for s, d in zip(srcs, dsts):
+        assert rel_err(d, s * 0.5) < 2e-3
+    assert int(flag) == 0
+    srcs[2][12345] = float("inf")
+    mt.scale(mt.TensorLists([srcs, dsts]), 0.5, noop_flag=flag)
+    assert int(flag) == 1
+    srcs[2][12345] = 0.0
+    tot, per = mt.l2norm(mt.TensorLists([srcs]), per_tensor=True)
+    ref = torch.sqrt(sum((s ** 2).sum() for s in srcs))
+    assert abs(tot.item() - ref.item()) < 1e-3 * ref.item()
+    assert rel_err(per, torch.stack([s.norm() for s in srcs])) < 1e-4
+
+
+def test_multi_tensor_axpby_and_flatten():
+    xs = [torch.randn(n, device=DEV) for n in (33, 4097)]
+    ys = [torch.randn(n, device=DEV) for n in (33, 4097)]
+    outs = [torch.empty(n, device=DEV) for n in (33, 4097)]
+    mt.axpby(mt.TensorLists([xs, ys, outs]), 2.0, -1.0)
+    for x, y, o in zip(xs, ys, outs):
+        assert rel_err(o, 2 * x - y) < 1e-6
+    flat = mt.flatten(xs, dtype=torch.float16)
+    assert rel_err(flat, torch.cat(xs)) < 2e-3
+    back = [torch.empty_like(x) for x in xs]
+    mt.unflatten(flat, back)
+    assert rel_err(back[1], xs[1]) < 2e-3
+
+
+@pytest.mark.parametrize("model_dtype", [None, torch.float16])
+def test_fused_sgd_matches_torch(model_dtype):
+    torch.manual_seed(10)
+    shapes = [(64, 3, 7, 7), (128,), (1000, 512), (3,)]
+    params = [torch.randn(s, device=DEV) for s in shapes]
+    ref_params = [p.clone().requires_grad_(True) for p in params]
+    opt = torch.optim.SGD(ref_params, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    bufs = [torch.zeros_like(p) for p in params]
+    grads = [torch.empty_like(p) for p in params]
+    lists = [grads, params, bufs]
+    models_ = None
+    if model_dtype is not None:
+        models_ = [torch.empty_like(p, dtype=model_dtype) for p in params]
+        lists.append(models_)
+    tl = mt.TensorLists(lists)
+    hp = torch.tensor([0.1, 0.9, 0.0, 1e-4, 0.0], device=DEV)
+    scale = torch.tensor([1024.0], device=DEV)
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    for step in range(3):
+        for g, rp in zip(grads, ref_params):
+            gr = torch.randn_like(g)
+            rp.grad = gr.clone()
+            g.copy_(gr * 1024.0)
+        opt.step()
+        mt.sgd(tl, hp, first_run=(step == 0), dev_scale=scale, noop_flag=flag)
+    for p, rp in zip(params, ref_params):
+        assert rel_err(p, rp) < 1e-5
+    if models_ is not None:
+        assert rel_err(models_[2], params[2]) < 2e-3
+    before = [p.clone() for p in params]
+    flag.fill_(1)
+    mt.sgd(tl, hp, first_run=False, dev_scale=scale, noop_flag=flag)
+    for p, b in zip(params, before):
+        assert torch.equal(p, b), "overflow flag must skip the step"
+
+
+def test_scaler_update_state_machine():
+    state = torch.tensor([65536.0, 0, 0, 0], device=DEV)
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    for _ in range(3):
+        mt.scaler_update(state, flag, 2.0, 0.5, 3, 1.0, 2.0 ** 24)
+    assert state[0].item() == 131072.0 and state[1].item() == 0
+    flag.fill_(1)
+    mt.scaler_update(state, flag, 2.0, 0.5, 3, 1.0, 2.0 ** 24)
+    assert state[0].item() == 65536.0 and state[2].item() == 1 and int(flag) == 0
+
+
+def test_dropout_mask_consistency():
+    x = torch.ones(64, 50, device=DEV, requires_grad=True)
+    y = ops.dropout(x, 0.5, True)
+    kept = (y != 0).float().mean().item()
+    assert 0.4 < kept < 0.6
+    assert torch.allclose(y[y != 0], torch.tensor(2.0, device=DEV))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad != 0, y != 0)
+    x2 = torch.ones(8, 6, 6, 20, device=DEV)
+    y2 = ops.dropout2d(x2, 0.5, True)
+    per_chan = (y2 != 0).float().mean((1, 2))
+    assert ((per_chan == 0) | (per_chan == 1)).all()
+
+
+def test_input_to_nhwc_normalise():
+    img = torch.randint(0, 256, (2, 3, 8, 10), device=DEV, dtype=torch.uint8)
+    mean = torch.tensor([0.4915, 0.4823, 0.4468], device=DEV)
+    std = torch.tensor([0.2470, 0.2435, 0.2616], device=DEV)
+    out = ops.input_to_nhwc(img, torch.float16, 4, (3, 3), 18, mean, 1.0 / std, 1.0 / 255)
+    ref = ((img.float() / 255 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)).permute(0, 2, 3, 1)
+    assert out.shape == (2, 14, 18, 4)
+    assert rel_err(out[:, 3:11, 3:13, :3], ref) < 2e-3
+    assert out[:, :3].abs().max() == 0 and out[..., 3].abs().max() == 0 and out[:, :, 13:].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("hw", [32, 64])
+def test_stem_matches_reference(dtype, hw):
+    torch.manual_seed(11)
+    m = models.resnet18().to(DEV).set_compute_dtype(dtype)
+    ref = models.torch_resnet("resnet18").to(DEV)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(4, 3, hw, hw, device=DEV)
+    out = ops.stem_conv_bn_relu_pool(x, m.conv1.weight, m.bn1.weight, m.bn1.bias, (2, 2), (3, 3), m.bn1.state(), dtype)
+    r = ref.maxpool(ref.relu(ref.bn1(ref.conv1(x)))).permute(0, 2, 3, 1)
+    assert rel_err(out, r) < TOL[dtype]
+    g = torch.randn_like(r)
+    out.backward(g.to(dtype))
+    r.backward(g)
+    assert rel_err(m.conv1.weight.grad, ref.conv1.weight.grad) < 3 * TOL[dtype]
+    assert rel_err(m.bn1.weight.grad, ref.bn1.weight.grad) < 3 * TOL[dtype]
+
+
+@pytest.mark.parametrize("arch,dtype,hw", [("resnet18", torch.float32, 32), ("resnet18", torch.float16, 32),
+                                           ("resnet50", torch.float16, 64), ("resnet50", torch.bfloat16, 64)])
+def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw):
+    torch.manual_seed(12)
+    m = models.get_model(arch).to(DEV).set_compute_dtype(dtype)
+    ref = models.torch_resnet(arch).to(DEV)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(8, 3, hw, hw, device=DEV)
+    t = torch.randint(0, 1000, (8,), device=DEV)
+    m.train(); ref.train()
+    loss = ops.cross_entropy(m(x), t)
+    lr = F.cross_entropy(ref(x), t)
+    assert abs(loss.item() - lr.item()) < (1e-3 if dtype == torch.float32 else 5e-2) * lr.item()
+    loss.backward()
+    lr.backward()
+    g, gr = dict(m.named_parameters()), dict(ref.named_parameters())
+    # compare by cosine similarity per tensor: low-precision runs differ element-wise but must point the same way
+    worst = 1.0
+    for k in g:
+        a, b = g[k].grad.float().flatten(), gr[k].grad.float().flatten()
+        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-12)
+        worst = min(worst, cos.item())
+    assert worst > (0.999 if dtype == torch.float32 else 0.95), worst
+
+
+def test_mnist_net_gpu_matches_cpu():
+    torch.manual_seed(13)
+    net = models.Net().eval()
+    x = torch.randn(5, 1, 28, 28)
+    ref = net(x)
+    out = net.to(DEV)(x.to(DEV))
+    assert rel_err(out.cpu(), ref) < 1e-4
+    net.train()
+    loss = ops.nll_loss(net(x.to(DEV)), torch.randint(0, 10, (5,), device=DEV))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_kernel_library_is_loaded():
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libpda_kernels.so" in maps
