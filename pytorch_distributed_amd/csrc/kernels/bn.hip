@@ -80,36 +80,60 @@ bn_stats_partial_kernel(const T* __restrict__ y, long long M, int C, float* __re
   }
 }
 
-// sums[0][c] = sum over partials, sums[1][c] = sum of squares (fp32 out, fp64 math)
-__global__ void bn_reduce_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
-                                          int nparts, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)psum[(long long)p * C + c];
-    q += (double)psq[(long long)p * C + c];
+// Reduce [nparts][C] partial sums to per-channel totals inside one block:
+// 1024 threads = 16 channels x 64 partial lanes (coalesced 64-byte row segments,
+// fp64 accumulation), then a 64-way LDS tree.  Returns the totals to the 16
+// threads with pl == 0.
+__device__ __forceinline__ void reduce_partials_16x64(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                      int nparts, int C, int c, int pl, double& ra, double& rb,
+                                                      double (*red)[64][17]) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    int p = pl;
+    for (; p + 192 < nparts; p += 256) {  // 4 independent loads in flight per array
+      const float a0 = pa[(long long)p * C + c], a1 = pa[(long long)(p + 64) * C + c];
+      const float a2 = pa[(long long)(p + 128) * C + c], a3 = pa[(long long)(p + 192) * C + c];
+      const float b0 = pb[(long long)p * C + c], b1 = pb[(long long)(p + 64) * C + c];
+      const float b2 = pb[(long long)(p + 128) * C + c], b3 = pb[(long long)(p + 192) * C + c];
+      a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; p < nparts; p += 64) {
+      a += (double)pa[(long long)p * C + c];
+      b += (double)pb[(long long)p * C + c];
+    }
   }
-  sums[c] = (float)s;
-  sums[C + c] = (float)q;
+  const int cl = threadIdx.x & 15;
+  red[0][pl][cl] = a;
+  red[1][pl][cl] = b;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (pl < s) {
+      red[0][pl][cl] += red[0][pl + s][cl];
+      red[1][pl][cl] += red[1][pl + s][cl];
+    }
+    __syncthreads();
+  }
+  ra = red[0][0][cl];
+  rb = red[1][0][cl];
 }
 
-// One thread per channel.  count = number of reduced elements per channel (over
-// all ranks for SyncBN).  Updates running stats in place (momentum, unbiased
-// variance) and emits mean / invstd / scale / shift.
-__global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
+// count = number of reduced elements per channel (over all ranks for SyncBN).
+// Updates running stats in place (momentum, unbiased variance) and emits
+// mean / invstd / scale / shift.  Grid = ceil(C/16) blocks of 1024 threads.
+__global__ void __launch_bounds__(1024)
+bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
                                    int C, double count, float eps, float momentum,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)psum[(long long)p * C + c];
-    q += (double)psq[(long long)p * C + c];
-  }
+  __shared__ double red[2][64][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int pl = threadIdx.x >> 4;
+  double s, q;
+  reduce_partials_16x64(psum, psq, nparts, C, c, pl, s, q, red);
+  if (pl != 0 || c >= C) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -127,6 +151,20 @@ __global__ void bn_finalize_kernel(const float* __restrict__ psum, const float* 
   }
 }
 
+// sums[0][c] = sum over partials, sums[1][c] = sum of squares (fp32 out, fp64 math)
+__global__ void __launch_bounds__(1024)
+bn_reduce_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts, int C,
+                          float* __restrict__ sums) {
+  __shared__ double red[2][64][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int pl = threadIdx.x >> 4;
+  double s, q;
+  reduce_partials_16x64(psum, psq, nparts, C, c, pl, s, q, red);
+  if (pl != 0 || c >= C) return;
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+}
+
 // Eval mode: scale/shift from running statistics.
 __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, const float* __restrict__ running_mean,
@@ -141,6 +179,8 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict_
   shift_out[c] = b - running_mean[c] * g * invstd;
 }
 
+// Every thread keeps one 16-byte channel vector for the whole grid-stride loop
+// (the stride is a multiple of the vectors per row), so scale/shift live in registers.
 template <typename T>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
@@ -148,16 +188,20 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
                 int relu) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % vpr) * EPC;
+  const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int c0 = (int)(i % vpr) * EPC;
+  float sc[EPC], sf[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e]; }
+  for (; i < nvec; i += stride) {
     Vec16<T> v = load16(y + i * EPC);
     Vec16<T> rv;
     if (res) rv = load16(res + i * EPC);
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float f = ElemTraits<T>::to_f32(v.v[e]) * scale[c0 + e] + shift[c0 + e];
+      float f = ElemTraits<T>::to_f32(v.v[e]) * sc[e] + sf[e];
       if (res) f += ElemTraits<T>::to_f32(rv.v[e]);
       if (relu) f = fmaxf(f, 0.f);
       o.v[e] = ElemTraits<T>::from_f32(f);
@@ -231,19 +275,29 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
   }
 }
 
+// dy = A[c]*g + B[c]*y + K[c]  with the three per-channel coefficients prepared by
+// bn_bwd_coefs_kernel (algebraically gamma*invstd*(g - dbeta/M - xhat*dgamma/M));
+// coef = [5][C] = {A, B, K, scale, shift}, all held in registers (see bn_apply_kernel).
 template <typename T>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
-                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                    const float* __restrict__ scale, const float* __restrict__ shift,
-                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                    const float* __restrict__ dbeta, long long nvec, int C, float inv_count, int relu,
+                    const float* __restrict__ coef, long long nvec, int C, int relu,
                     T* __restrict__ dy, T* __restrict__ dres) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % vpr) * EPC;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int c0 = (int)(i % vpr) * EPC;
+  float cA[EPC], cB[EPC], cK[EPC], sc[EPC], sf[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    cA[e] = coef[c0 + e];
+    cB[e] = coef[C + c0 + e];
+    cK[e] = coef[2 * C + c0 + e];
+    sc[e] = coef[3 * C + c0 + e];
+    sf[e] = coef[4 * C + c0 + e];
+  }
+  for (; i < nvec; i += stride) {
     Vec16<T> vd = load16(dout + i * EPC);
     Vec16<T> vy = load16(y + i * EPC);
     Vec16<T> vo;
@@ -251,17 +305,13 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
     Vec16<T> o, og;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      const int c = c0 + e;
       float gd = ElemTraits<T>::to_f32(vd.v[e]);
       const float yv = ElemTraits<T>::to_f32(vy.v[e]);
       if (relu) {
-        const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * scale[c] + shift[c] > 0.f);
+        const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * sc[e] + sf[e] > 0.f);
         gd = pos ? gd : 0.f;
       }
-      const float xhat = (yv - mean[c]) * invstd[c];
-      const float gm = gamma ? gamma[c] : 1.f;
-      const float r = gm * invstd[c] * (gd - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count);
-      o.v[e] = ElemTraits<T>::from_f32(r);
+      o.v[e] = ElemTraits<T>::from_f32(cA[e] * gd + cB[e] * yv + cK[e]);
       og.v[e] = ElemTraits<T>::from_f32(gd);
     }
     store16(dy + i * EPC, o);
@@ -269,18 +319,46 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
   }
 }
 
-// out[c] = sum_p in[p][c] for two arrays at once (dgamma / dbeta partials).
-__global__ void reduce2_partials_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts,
-                                        int C, float* __restrict__ oa, float* __restrict__ ob) {
+// Reduce the dgamma / dbeta partials and (when coef != null) emit the backward
+// coefficients in the same launch.  For SyncBN the totals are all-reduced first and
+// bn_bwd_coefs_kernel runs separately on the global sums.
+__device__ __forceinline__ void bwd_coefs(int c, int C, float dg, float db, const float* mean, const float* invstd,
+                                          const float* scale, const float* shift, const float* gamma,
+                                          float inv_count, float* coef) {
+  const float gm = gamma ? gamma[c] : 1.f;
+  const float is = invstd[c];
+  const float A = gm * is;
+  const float B = -A * is * dg * inv_count;
+  coef[c] = A;
+  coef[C + c] = B;
+  coef[2 * C + c] = -A * db * inv_count - B * mean[c];
+  coef[3 * C + c] = scale[c];
+  coef[4 * C + c] = shift[c];
+}
+
+__global__ void __launch_bounds__(1024)
+bn_bwd_finalize_kernel(const float* __restrict__ pdg, const float* __restrict__ pdb, int nparts, int C,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ mean,
+                       const float* __restrict__ invstd, const float* __restrict__ scale,
+                       const float* __restrict__ shift, const float* __restrict__ gamma, float inv_count,
+                       float* __restrict__ coef) {
+  __shared__ double red[2][64][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int pl = threadIdx.x >> 4;
+  double a, b;
+  reduce_partials_16x64(pdg, pdb, nparts, C, c, pl, a, b, red);
+  if (pl != 0 || c >= C) return;
+  dgamma[c] = (float)a;
+  dbeta[c] = (float)b;
+  if (coef) bwd_coefs(c, C, (float)a, (float)b, mean, invstd, scale, shift, gamma, inv_count, coef);
+}
+
+__global__ void bn_bwd_coefs_kernel(const float* __restrict__ dg, const float* __restrict__ db, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ gamma, float inv_count, float* __restrict__ coef) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int p = 0; p < nparts; ++p) {
-    a += pa[(long long)p * C + c];
-    b += pb[(long long)p * C + c];
-  }
-  oa[c] = a;
-  ob[c] = b;
+  if (c < C) bwd_coefs(c, C, dg[c], db[c], mean, invstd, scale, shift, gamma, inv_count, coef);
 }
 
 // ------------------------------------------------------------- host side ----
@@ -320,7 +398,7 @@ PDA_EXPORT int pda_bn_stats_partial(int dtype, const void* y, long long M, int C
 
 PDA_EXPORT int pda_bn_reduce_partials(const float* psum, const float* psq, int nparts, int C, float* sums,
                                       hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, st, psum, psq, nparts, C,
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C,
                      sums);
   return pda_check_launch();
 }
@@ -329,7 +407,7 @@ PDA_EXPORT int pda_bn_finalize(const float* psum, const float* psq, int nparts, 
                                float momentum, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float* mean_out, float* invstd_out, float* scale_out,
                                float* shift_out, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, psum, psq, nparts, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
                      eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
                      shift_out);
   return pda_check_launch();
@@ -343,10 +421,16 @@ PDA_EXPORT int pda_bn_eval_coeffs(int C, float eps, const float* gamma, const fl
   return pda_check_launch();
 }
 
-static inline int ew_blocks(long long nvec) {
+// Grid for the register-resident-coefficient kernels: blocks*256 must be a multiple of
+// the vectors per row so a thread's channel vector never changes along its loop.
+static inline int ew_blocks_chan(long long nvec, int vpr) {
   long long b = (nvec + 255) / 256;
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
+  long long g = vpr, r = 256;
+  while (r) { const long long t = g % r; g = r; r = t; }  // gcd(vpr, 256)
+  const long long m = vpr / g;                             // blocks must be a multiple of m
+  b = ((b + m - 1) / m) * m;
   return (int)b;
 }
 
@@ -356,7 +440,8 @@ PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out
   if (C % (16 / es) != 0) return -1;
   const long long nvec = M * C / (16 / es);
   if (nvec == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(nvec)), dim3(256), 0, st,
+  const int vpr = C / (16 / es);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
                                            (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu));
   return pda_check_launch();
 }
@@ -374,23 +459,33 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
   return pda_check_launch();
 }
 
-PDA_EXPORT int pda_reduce2_partials(const float* pa, const float* pb, int nparts, int C, float* oa, float* ob,
-                                    hipStream_t st) {
-  hipLaunchKernelGGL(reduce2_partials_kernel, dim3((C + 127) / 128), dim3(128), 0, st, pa, pb, nparts, C, oa, ob);
+// Reduce dgamma/dbeta partials; with coef != null also emits the bwd-apply coefficients ([5][C]).
+PDA_EXPORT int pda_bn_bwd_finalize(const float* pdg, const float* pdb, int nparts, int C, float* dgamma,
+                                   float* dbeta, const float* mean, const float* invstd, const float* scale,
+                                   const float* shift, const float* gamma, double count, float* coef,
+                                   hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, pdg, pdb, nparts, C, dgamma,
+                     dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef);
   return pda_check_launch();
 }
 
-PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* mean,
-                                const float* invstd, const float* scale, const float* shift, const float* gamma,
-                                const float* dgamma, const float* dbeta, long long M, int C, double count,
-                                int relu, void* dy, void* dres, hipStream_t st) {
+PDA_EXPORT int pda_bn_bwd_coefs(const float* dg, const float* db, int C, const float* mean, const float* invstd,
+                                const float* scale, const float* shift, const float* gamma, double count,
+                                float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((C + 127) / 128), dim3(128), 0, st, dg, db, C, mean, invstd, scale,
+                     shift, gamma, (float)(1.0 / count), coef);
+  return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* coef,
+                                long long M, int C, int relu, void* dy, void* dres, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0) return -1;
   const long long nvec = M * C / (16 / es);
   if (nvec == 0) return 0;
-  const float inv_count = (float)(1.0 / count);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(nvec)), dim3(256), 0, st,
-                                           (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift,
-                                           gamma, dgamma, dbeta, nvec, C, inv_count, relu, (T*)dy, (T*)dres));
+  const int vpr = C / (16 / es);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
+                                           st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, relu,
+                                           (T*)dy, (T*)dres));
   return pda_check_launch();
 }

@@ -42,9 +42,9 @@ _SIGS = {
     "pda_bn_eval_coeffs": [c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "pda_bn_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_bn_bwd_reduce": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
-    "pda_reduce2_partials": [c_p, c_p, c_i, c_i, c_p, c_p, c_p],
-    "pda_bn_bwd_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_d, c_i, c_p, c_p,
-                         c_p],
+    "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p],
+    "pda_bn_bwd_coefs": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p],
+    "pda_bn_bwd_apply": [c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
     "pda_maxpool_fwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_maxpool_bwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_gap_fwd": [c_i, c_p, c_p, c_i, c_i, c_i, c_p],

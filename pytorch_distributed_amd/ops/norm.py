@@ -116,19 +116,23 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                                    invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C, int(relu),
                                    part[0].data_ptr(), part[1].data_ptr(), _lib.stream()), "pda_bn_bwd_reduce")
     dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
-    _lib.check(l.pda_reduce2_partials(part[0].data_ptr(), part[1].data_ptr(), n, C, dgb[0].data_ptr(),
-                                      dgb[1].data_ptr(), _lib.stream()), "pda_reduce2_partials")
-    dg_tot = dgb
-    if _world(group) > 1:
+    coef = torch.empty((5, C), device=dev, dtype=torch.float32)
+    sync = _world(group) > 1
+    _lib.check(l.pda_bn_bwd_finalize(part[0].data_ptr(), part[1].data_ptr(), n, C, dgb[0].data_ptr(),
+                                     dgb[1].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                     shift.data_ptr(), _lib.ptr(gamma), float(count),
+                                     0 if sync else coef.data_ptr(), _lib.stream()), "pda_bn_bwd_finalize")
+    if sync:
         import torch.distributed as dist
-        dg_tot = dgb.clone()
-        dist.all_reduce(dg_tot, group=group)  # dx needs the global sums; the parameter grads stay local
+        tot = dgb.clone()
+        dist.all_reduce(tot, group=group)  # dx needs the global sums; the parameter grads stay local
+        _lib.check(l.pda_bn_bwd_coefs(tot[0].data_ptr(), tot[1].data_ptr(), C, mean.data_ptr(), invstd.data_ptr(),
+                                      scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma), float(count),
+                                      coef.data_ptr(), _lib.stream()), "pda_bn_bwd_coefs")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
-                                  invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma),
-                                  dg_tot[0].data_ptr(), dg_tot[1].data_ptr(), M, C, float(count), int(relu),
-                                  dy.data_ptr(), _lib.ptr(dres), _lib.stream()), "pda_bn_bwd_apply")
+    _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), coef.data_ptr(),
+                                  M, C, int(relu), dy.data_ptr(), _lib.ptr(dres), _lib.stream()), "pda_bn_bwd_apply")
     return dy, dres, dgb[0], dgb[1]
 
 
