@@ -1,0 +1,230 @@
+"""Process bootstrap: rank discovery, rendezvous and process-group creation.
+
+One entry point, ``init_process_group``, covers the reference's three rendezvous styles:
+``env://`` under a launcher (/root/reference/2.distributed.py:98), ``tcp://127.0.0.1:23456``
+with explicit rank/world (/root/reference/3.multiprocessing_distributed.py:102) and
+``file://<path>.<jobid>`` on a shared filesystem under SLURM
+(/root/reference/6.distributed_slurm_main.py:93-101).  The key-value rendezvous runs on this
+package's native stores (``csrc/runtime/store.cc``), wrapped as a c10d ``Store`` so the RCCL
+unique-id exchange and gloo's pairing use them; collectives run on ``torch.distributed``
+(backend ``"nccl"`` = RCCL over xGMI on GPUs, ``"gloo"`` on CPU tensors).
+``backend="rccl"`` is accepted as an alias of ``"nccl"``.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .store import TCPStore, FileStore, PrefixStore, Store, StoreTimeout, store_barrier, Heartbeat  # noqa: F401
+
+_STATE = {"store": None, "info": None, "heartbeat": None}
+
+
+@dataclass
+class RankInfo:
+    rank: int = 0
+    world_size: int = 1
+    local_rank: int = 0
+    local_size: int = 1
+    node_rank: int = 0
+    num_nodes: int = 1
+    master_addr: str = "127.0.0.1"
+    master_port: int = 29500
+    source: str = "single"
+
+
+def _first(*names, default=None):
+    for n in names:
+        v = os.environ.get(n)
+        if v not in (None, ""):
+            return v
+    return default
+
+
+def discover(local_rank_arg: Optional[int] = None, gpus_per_task: Optional[int] = None) -> RankInfo:
+    """Work out who we are from whichever launcher started us.
+
+    Order: torchrun/launch env (RANK/WORLD_SIZE/LOCAL_RANK), Horovod-style env
+    (HOROVOD_RANK..., OMPI_COMM_WORLD_*), SLURM (SLURM_PROCID/NTASKS/LOCALID - or, when one
+    task per node spawns its own workers as the reference's script 6 does, call
+    ``slurm_world(gpus_per_task)``), then a single process.
+    """
+    e = os.environ
+    addr = e.get("MASTER_ADDR", "127.0.0.1")
+    port = int(e.get("MASTER_PORT", "29500"))
+    if "RANK" in e and "WORLD_SIZE" in e:
+        lr = int(e.get("LOCAL_RANK", local_rank_arg if local_rank_arg not in (None, -1) else 0))
+        ls = int(e.get("LOCAL_WORLD_SIZE", e.get("WORLD_SIZE")))
+        return RankInfo(int(e["RANK"]), int(e["WORLD_SIZE"]), lr, ls, int(e.get("GROUP_RANK", 0)),
+                        max(1, int(e["WORLD_SIZE"]) // max(ls, 1)), addr, port, "env")
+    r = _first("HOROVOD_RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK")
+    if r is not None:
+        w = int(_first("HOROVOD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", default="1"))
+        lr = int(_first("HOROVOD_LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", default=r))
+        ls = int(_first("HOROVOD_LOCAL_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", default=str(w)))
+        return RankInfo(int(r), w, lr, ls, int(r) // max(ls, 1), max(1, w // max(ls, 1)), addr, port, "horovod")
+    if "SLURM_PROCID" in e and gpus_per_task is None:
+        w = int(_first("SLURM_NTASKS", "SLURM_NPROCS", default="1"))
+        lr = int(e.get("SLURM_LOCALID", 0))
+        nn = int(e.get("SLURM_NNODES", 1))
+        return RankInfo(int(e["SLURM_PROCID"]), w, lr, max(1, w // max(nn, 1)), int(e.get("SLURM_NODEID", 0)), nn,
+                        _slurm_master(addr), port, "slurm")
+    if local_rank_arg not in (None, -1):
+        return RankInfo(local_rank_arg, int(e.get("WORLD_SIZE", 1)), local_rank_arg, source="argv")
+    return RankInfo(master_addr=addr, master_port=port)
+
+
+def _slurm_master(default: str) -> str:
+    nl = os.environ.get("SLURM_STEP_NODELIST") or os.environ.get("SLURM_JOB_NODELIST") or ""
+    if not nl:
+        return default
+    head = nl.split(",")[0]
+    if "[" in head:  # prefix[a-b,...] -> prefixa
+        pre, rest = head.split("[", 1)
+        head = pre + rest.split("-")[0].split(",")[0].rstrip("]")
+    return os.environ.get("MASTER_ADDR", head)
+
+
+def slurm_world(gpus_per_task: int, local_gpu: int) -> RankInfo:
+    """One SLURM task per node that spawns ``gpus_per_task`` workers (script 6's scheme) - with the
+    world size computed as tasks x gpus (the reference uses the task count alone, which is only
+    right for 1 GPU per node: /root/reference/6.distributed_slurm_main.py:89-100)."""
+    e = os.environ
+    node = int(e.get("SLURM_PROCID", 0))
+    ntasks = int(_first("SLURM_NTASKS", "SLURM_NPROCS", default="1"))
+    return RankInfo(node * gpus_per_task + local_gpu, ntasks * gpus_per_task, local_gpu, gpus_per_task, node, ntasks,
+                    _slurm_master("127.0.0.1"), int(e.get("MASTER_PORT", "29500")), "slurm-spawn")
+
+
+class C10dStoreAdapter(dist.Store):
+    """Expose a native store of this package through the c10d ``Store`` interface."""
+
+    def __init__(self, native):
+        super().__init__()
+        self._n = native
+        self._timeout = datetime.timedelta(seconds=native.timeout)
+
+    def set(self, key, value):
+        self._n.set(key, value)
+
+    def get(self, key):
+        return self._n.get(key, self._timeout.total_seconds())
+
+    def add(self, key, value):
+        return self._n.add(key, value)
+
+    def wait(self, keys, timeout=None):
+        t = self._timeout if timeout is None else timeout
+        self._n.wait(list(keys), t.total_seconds() if hasattr(t, "total_seconds") else float(t))
+
+    def check(self, keys):
+        return self._n.check(list(keys))
+
+    def delete_key(self, key):
+        return self._n.delete_key(key)
+
+    def num_keys(self):
+        return self._n.num_keys()
+
+    def compare_set(self, key, expected, desired):
+        return self._n.compare_set(key, expected, desired)
+
+    def set_timeout(self, timeout):
+        self._timeout = timeout
+
+    @property
+    def timeout(self):
+        return self._timeout
+
+
+def _make_store(init_method: str, rank: int, world_size: int, timeout_s: float):
+    if init_method.startswith("tcp://"):
+        hostport = init_method[len("tcp://"):].split("?")[0]
+        host, port = hostport.rsplit(":", 1)
+        return TCPStore(host, int(port), world_size, is_master=(rank == 0), timeout=timeout_s)
+    if init_method.startswith("file://"):
+        return FileStore(init_method[len("file://"):], world_size, timeout=timeout_s)
+    if init_method.startswith("env://"):
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500"))
+        return TCPStore(host, port, world_size, is_master=(rank == 0), timeout=timeout_s)
+    raise ValueError(f"unsupported init_method {init_method!r} (use env://, tcp://host:port or file://path)")
+
+
+def init_process_group(backend: Optional[str] = None, init_method: Optional[str] = None, world_size: int = -1,
+                       rank: int = -1, timeout: Optional[datetime.timedelta] = None, store=None,
+                       device_id: Optional[torch.device] = None, heartbeat: bool = False) -> RankInfo:
+    """Create the default process group; returns the resolved ``RankInfo``."""
+    info = discover()
+    if rank >= 0:
+        info.rank = rank
+    if world_size > 0:
+        info.world_size = world_size
+    if backend in (None, ""):
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend.lower() in ("rccl", "nccl"):
+        backend = "nccl"
+    init_method = init_method or "env://"
+    timeout = timeout or datetime.timedelta(seconds=float(os.environ.get("PDA_DIST_TIMEOUT_S", "600")))
+    kw = {}
+    if device_id is not None and backend == "nccl":
+        kw["device_id"] = device_id
+    use_native = os.environ.get("PDA_NATIVE_STORE", "1") == "1" and store is None
+    if use_native:
+        native = _make_store(init_method, info.rank, info.world_size, timeout.total_seconds())
+        _STATE["store"] = native
+        store = C10dStoreAdapter(PrefixStore("c10d", native))
+        if heartbeat:
+            _STATE["heartbeat"] = Heartbeat(PrefixStore("pda", native), info.rank)
+    if store is not None:
+        dist.init_process_group(backend, store=store, rank=info.rank, world_size=info.world_size, timeout=timeout,
+                                **kw)
+    else:
+        dist.init_process_group(backend, init_method=init_method, rank=info.rank, world_size=info.world_size,
+                                timeout=timeout, **kw)
+    _STATE["info"] = info
+    return info
+
+
+def native_store():
+    """The package's rendezvous store behind the default group (None if torch's own was used)."""
+    return _STATE["store"]
+
+
+def rank_info() -> Optional[RankInfo]:
+    return _STATE["info"]
+
+
+def destroy_process_group() -> None:
+    if _STATE["heartbeat"] is not None:
+        _STATE["heartbeat"].stop()
+        _STATE["heartbeat"] = None
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    st = _STATE["store"]
+    _STATE["store"] = None
+    if st is not None:
+        st.close()
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+__all__ = ["RankInfo", "discover", "slurm_world", "init_process_group", "destroy_process_group", "native_store",
+           "rank_info", "get_rank", "get_world_size", "barrier", "TCPStore", "FileStore", "PrefixStore", "Store",
+           "StoreTimeout", "store_barrier", "Heartbeat", "C10dStoreAdapter"]

@@ -236,12 +236,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
     const long long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
     const long long r0 = blockIdx.x * rows_per_blk;
     const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
-    for (long long r = r0 + g.rl; r < r1; r += g.RS) {
-      const long long o = r * C + (long long)g.vec * EPC;
-      Vec16<T> vd = load16(dout + o);
-      Vec16<T> vy = load16(y + o);
-      Vec16<T> vo;
-      if (relu && out) vo = load16(out + o);
+    auto accum = [&](const Vec16<T>& vd, const Vec16<T>& vy, const Vec16<T>& vo) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         float gd = ElemTraits<T>::to_f32(vd.v[e]);
@@ -253,6 +248,29 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
         db[e] += gd;
         dg[e] += gd * (yv - mu[e]) * is[e];
       }
+    };
+    const bool need_out = relu && out;
+    long long r = r0 + g.rl;
+    // four rows in flight per thread: the loop is latency-bound otherwise
+    for (; r + 3 * g.RS < r1; r += 4 * g.RS) {
+      Vec16<T> vd[4], vy[4], vo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long o = (r + (long long)u * g.RS) * C + (long long)g.vec * EPC;
+        vd[u] = load16(dout + o);
+        vy[u] = load16(y + o);
+        if (need_out) vo[u] = load16(out + o);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(vd[u], vy[u], vo[u]);
+    }
+    for (; r < r1; r += g.RS) {
+      const long long o = r * C + (long long)g.vec * EPC;
+      Vec16<T> vd = load16(dout + o);
+      Vec16<T> vy = load16(y + o);
+      Vec16<T> vo;
+      if (need_out) vo = load16(out + o);
+      accum(vd, vy, vo);
     }
   }
 #pragma unroll
@@ -381,7 +399,7 @@ static inline int col_blocks_y(int C, int es) {
 // Number of row-partials a reduce over M rows will produce (python allocates [n][C]).
 PDA_EXPORT int pda_bn_num_partials(long long M) {
   long long n = (M + 255) / 256;
-  if (n > 512) n = 512;
+  if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
 }

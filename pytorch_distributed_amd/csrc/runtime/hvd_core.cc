@@ -1,0 +1,411 @@
+// Horovod-style collective engine: what `hvd.init()` starts and what
+// `hvd.allreduce_async_ / broadcast_async_ / synchronize / poll` talk to in the reference
+// (/root/reference/5.horovod_distributed.py:92,116-125, /root/reference/5.2.horovod_pytorch_mnist.py:77,174-185).
+//
+// * Every rank owns a background thread.  User threads only enqueue named requests
+//   and get integer handles back.
+// * Each cycle the threads exchange their lists of pending request names
+//   (variable-length all-gather over the shared-memory control plane).  A tensor is
+//   READY once every rank has announced the same name with the same
+//   kind/dtype/op/count/root; ranks may enqueue in different orders - the execution
+//   order is rank 0's announcement order, identical everywhere because every rank
+//   evaluates the same gathered lists.  Mismatched metadata fails the handle with a
+//   message instead of hanging.
+// * Consecutive ready all-reduces with equal (dtype, op, device, scales) are FUSED
+//   up to the fusion threshold (64 MiB default): CPU tensors are packed into the
+//   fusion buffer, reduced with one shared-memory all-reduce and unpacked with the
+//   post-scale applied (average = sum * 1/size, exactly once).  Device tensors are
+//   handed, group by group, to an executor callback (python: one flatten kernel +
+//   one RCCL all-reduce on a side stream + one unflatten kernel).
+// * A shutdown request travels with the same exchange, so all threads leave together.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define PDA_EXPORT extern "C" __attribute__((visibility("default")))
+
+extern "C" {
+long long pda_shm_all_reduce_async(void* h, void* buf, long long count, int dtype, int op);
+long long pda_shm_broadcast_async(void* h, void* buf, long long bytes, int root);
+long long pda_shm_all_gather_async(void* h, const void* in, void* out, long long bytes);
+int pda_shm_wait(void* h, long long ticket);
+}
+
+namespace {
+
+enum Kind : int { K_ALLREDUCE = 0, K_BROADCAST = 1 };
+enum HOp : int { H_SUM = 0, H_PROD = 1, H_MIN = 2, H_MAX = 3, H_AVG = 4 };
+
+size_t dsize(int dt) {
+  switch (dt) {
+    case 0: case 5: return 4;
+    case 1: case 2: return 2;
+    case 3: return 1;
+    default: return 8;
+  }
+}
+
+struct Request {
+  long long handle;
+  std::string name;
+  int kind, dtype, op, root, device;
+  void* ptr;
+  long long count;
+  double prescale, postscale;
+  bool announced = false;
+};
+
+struct Status {
+  int state = 0;  // 0 pending, 1 done, -1 failed
+  std::string error;
+};
+
+typedef int (*ExecFn)(int kind, int n, const long long* handles, int op, int root);
+
+class Engine {
+ public:
+  Engine(void* shm, int rank, int world, long long fusion_bytes, double cycle_ms, ExecFn exec)
+      : shm_(shm), rank_(rank), world_(world), fusion_bytes_(fusion_bytes), cycle_ms_(cycle_ms), exec_(exec) {
+    fusion_.resize((size_t)std::max<long long>(fusion_bytes, 1 << 20));
+    th_ = std::thread([this] { loop(); });
+  }
+  ~Engine() { shutdown(); }
+
+  long long enqueue(const char* name, int kind, void* ptr, long long count, int dtype, int op, int root, int device,
+                    double prescale, double postscale) {
+    std::lock_guard<std::mutex> g(mu_);
+    Request r;
+    r.handle = ++next_handle_;
+    r.name = name;
+    r.kind = kind; r.dtype = dtype; r.op = op; r.root = root; r.device = device;
+    r.ptr = ptr; r.count = count; r.prescale = prescale; r.postscale = postscale;
+    for (auto& q : queue_)
+      if (q.name == r.name) {
+        status_[r.handle].state = -1;
+        status_[r.handle].error = "a request named '" + r.name + "' is already pending on this rank";
+        cv_.notify_all();
+        return r.handle;
+      }
+    status_[r.handle] = Status();
+    queue_.push_back(r);
+    cv_.notify_all();
+    return r.handle;
+  }
+  int poll(long long h) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = status_.find(h);
+    return it == status_.end() ? 1 : it->second.state;
+  }
+  int wait(long long h, char* err, int cap) {
+    std::unique_lock<std::mutex> g(mu_);
+    cv_.wait(g, [&] {
+      auto it = status_.find(h);
+      return it == status_.end() || it->second.state != 0 || dead_;
+    });
+    auto it = status_.find(h);
+    if (it == status_.end()) return 0;
+    int st = it->second.state;
+    if (st == 0 && dead_) {
+      st = -1;
+      it->second.error = "engine stopped before the request completed";
+    }
+    if (st < 0 && err && cap > 0) {
+      strncpy(err, it->second.error.c_str(), (size_t)cap - 1);
+      err[cap - 1] = 0;
+    }
+    status_.erase(it);
+    return st < 0 ? -1 : 0;
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_requested_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+  }
+  // python executor reports the fate of a device group
+  void* request_ptr(long long h) { auto it = inflight_.find(h); return it == inflight_.end() ? nullptr : it->second.ptr; }
+  long long request_count(long long h) { auto it = inflight_.find(h); return it == inflight_.end() ? 0 : it->second.count; }
+  double request_postscale(long long h) { auto it = inflight_.find(h); return it == inflight_.end() ? 1.0 : it->second.postscale; }
+  double request_prescale(long long h) { auto it = inflight_.find(h); return it == inflight_.end() ? 1.0 : it->second.prescale; }
+  long long cycles() const { return cycles_.load(); }
+  long long fused_groups() const { return groups_.load(); }
+
+ private:
+  static void put(std::string& s, const void* p, size_t n) { s.append(static_cast<const char*>(p), n); }
+
+  bool gather_bytes(const std::string& mine, std::vector<std::string>* all) {
+    long long n = (long long)mine.size();
+    std::vector<long long> lens((size_t)world_);
+    if (pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, &n, lens.data(), 8)) != 0) return false;
+    long long m = 1;
+    for (long long l : lens) m = std::max(m, l);
+    std::string pad = mine;
+    pad.resize((size_t)m, '\0');
+    std::string out((size_t)m * (size_t)world_, '\0');
+    if (pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, pad.data(), &out[0], m)) != 0) return false;
+    all->clear();
+    for (int r = 0; r < world_; ++r) all->push_back(out.substr((size_t)r * (size_t)m, (size_t)lens[(size_t)r]));
+    return true;
+  }
+
+  struct Meta { int kind, dtype, op, root, device; long long count; };
+
+  static void parse(const std::string& s, bool* stop, std::vector<std::pair<std::string, Meta>>* out) {
+    size_t p = 0;
+    *stop = s.size() > 0 && s[0] != 0;
+    p = 1;
+    while (p + 4 <= s.size()) {
+      uint32_t nl;
+      memcpy(&nl, s.data() + p, 4);
+      p += 4;
+      if (p + nl + sizeof(Meta) > s.size()) break;
+      std::string name = s.substr(p, nl);
+      p += nl;
+      Meta m;
+      memcpy(&m, s.data() + p, sizeof(Meta));
+      p += sizeof(Meta);
+      out->push_back({name, m});
+    }
+  }
+
+  void finish(long long h, int state, const std::string& err = "") {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = status_.find(h);
+    if (it != status_.end()) {
+      it->second.state = state;
+      it->second.error = err;
+    }
+    cv_.notify_all();
+  }
+
+  template <typename F> static void scale_buf(void* p, long long n, int dt, double s, F) {
+    if (s == 1.0) return;
+    if (dt == 0) { float* f = (float*)p; for (long long i = 0; i < n; ++i) f[i] = (float)(f[i] * s); }
+    else if (dt == 4) { double* f = (double*)p; for (long long i = 0; i < n; ++i) f[i] *= s; }
+    else if (dt == 5) { int32_t* f = (int32_t*)p; for (long long i = 0; i < n; ++i) f[i] = (int32_t)(f[i] * s); }
+    else if (dt == 6) { int64_t* f = (int64_t*)p; for (long long i = 0; i < n; ++i) f[i] = (int64_t)(f[i] * s); }
+  }
+
+  void run_cpu_group(std::vector<Request>& grp) {
+    const int dt = grp[0].dtype;
+    const size_t es = dsize(dt);
+    const int op = grp[0].op;  // H_AVG maps onto the shm backend's AVG (sum, then /world once)
+    if (grp.size() == 1) {  // large or lonely tensor: reduce in place
+      Request& r = grp[0];
+      scale_buf(r.ptr, r.count, dt, r.prescale, 0);
+      int rc = pda_shm_wait(shm_, pda_shm_all_reduce_async(shm_, r.ptr, r.count, dt, op));
+      scale_buf(r.ptr, r.count, dt, r.postscale, 0);
+      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-reduce failed");
+      return;
+    }
+    size_t off = 0;
+    for (auto& r : grp) {
+      memcpy(&fusion_[off], r.ptr, (size_t)r.count * es);
+      scale_buf(&fusion_[off], r.count, dt, r.prescale, 0);
+      off += (size_t)r.count * es;
+    }
+    int rc = pda_shm_wait(shm_, pda_shm_all_reduce_async(shm_, fusion_.data(), (long long)(off / es), dt, op));
+    off = 0;
+    for (auto& r : grp) {
+      scale_buf(&fusion_[off], r.count, dt, r.postscale, 0);
+      memcpy(r.ptr, &fusion_[off], (size_t)r.count * es);
+      off += (size_t)r.count * es;
+      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-reduce failed");
+    }
+  }
+
+  void run_device_group(std::vector<Request>& grp) {
+    std::vector<long long> hs;
+    for (auto& r : grp) {
+      hs.push_back(r.handle);
+      inflight_[r.handle] = r;
+    }
+    int rc = exec_ ? exec_(grp[0].kind, (int)hs.size(), hs.data(), grp[0].op, grp[0].root) : -1;
+    for (auto& r : grp) {
+      inflight_.erase(r.handle);
+      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "device executor failed (no executor registered?)");
+    }
+  }
+
+  void execute(std::vector<Request>& ready) {
+    size_t i = 0;
+    while (i < ready.size()) {
+      Request& r = ready[i];
+      if (r.kind == K_BROADCAST) {
+        if (r.device == 0) {
+          int rc = pda_shm_wait(shm_, pda_shm_broadcast_async(shm_, r.ptr, r.count * (long long)dsize(r.dtype), r.root));
+          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory broadcast failed");
+        } else {
+          std::vector<Request> g1{r};
+          run_device_group(g1);
+        }
+        ++i;
+        continue;
+      }
+      std::vector<Request> grp{r};
+      long long bytes = r.count * (long long)dsize(r.dtype);
+      size_t j = i + 1;
+      while (j < ready.size()) {
+        Request& n = ready[j];
+        const long long nb = n.count * (long long)dsize(n.dtype);
+        if (n.kind != K_ALLREDUCE || n.dtype != r.dtype || n.op != r.op || n.device != r.device ||
+            n.prescale != r.prescale || n.postscale != r.postscale || bytes + nb > fusion_bytes_)
+          break;
+        grp.push_back(n);
+        bytes += nb;
+        ++j;
+      }
+      groups_.fetch_add(1);
+      if (r.device == 0) run_cpu_group(grp);
+      else run_device_group(grp);
+      i = j;
+    }
+  }
+
+  void loop() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait_for(g, std::chrono::microseconds((long long)(cycle_ms_ * 1000)),
+                     [&] { return stop_requested_ || !queue_.empty(); });
+      }
+      cycles_.fetch_add(1);
+      std::string mine;
+      std::vector<Request> snapshot;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        mine.push_back(stop_requested_ ? 1 : 0);
+        for (auto& r : queue_) {
+          uint32_t nl = (uint32_t)r.name.size();
+          put(mine, &nl, 4);
+          mine.append(r.name);
+          Meta m;
+          memset(&m, 0, sizeof(m));  // padding bytes take part in the cross-rank memcmp
+          m.kind = r.kind; m.dtype = r.dtype; m.op = r.op; m.root = r.root; m.device = r.device; m.count = r.count;
+          put(mine, &m, sizeof(m));
+        }
+        snapshot.assign(queue_.begin(), queue_.end());
+      }
+      std::vector<std::string> all;
+      if (!gather_bytes(mine, &all)) {
+        fail_everything("control-plane exchange failed (a peer died or timed out)");
+        return;
+      }
+      bool all_stop = true, any_stop = false;
+      std::vector<std::vector<std::pair<std::string, Meta>>> lists((size_t)world_);
+      for (int r = 0; r < world_; ++r) {
+        bool st = false;
+        parse(all[(size_t)r], &st, &lists[(size_t)r]);
+        all_stop = all_stop && st;
+        any_stop = any_stop || st;
+      }
+      // ready = announced by everybody; order = rank 0's
+      std::vector<Request> ready;
+      for (auto& ent : lists[0]) {
+        bool everywhere = true, consistent = true;
+        for (int r = 1; r < world_ && everywhere; ++r) {
+          bool found = false;
+          for (auto& e2 : lists[(size_t)r])
+            if (e2.first == ent.first) {
+              found = true;
+              if (memcmp(&e2.second, &ent.second, sizeof(Meta)) != 0) consistent = false;
+              break;
+            }
+          everywhere = found;
+        }
+        if (!everywhere) continue;
+        for (auto& rq : snapshot)
+          if (rq.name == ent.first) {
+            if (!consistent) {
+              remove_from_queue(rq.handle);
+              finish(rq.handle, -1, "tensor '" + rq.name + "' was submitted with different type/shape/op on different ranks");
+            } else {
+              ready.push_back(rq);
+              remove_from_queue(rq.handle);
+            }
+            break;
+          }
+      }
+      if (!ready.empty()) execute(ready);
+      if (all_stop || (any_stop && ready.empty() && all_queues_empty(lists))) {
+        std::lock_guard<std::mutex> g(mu_);
+        dead_ = true;
+        cv_.notify_all();
+        return;
+      }
+    }
+  }
+  static bool all_queues_empty(const std::vector<std::vector<std::pair<std::string, Meta>>>& l) {
+    for (auto& v : l)
+      if (!v.empty()) return false;
+    return true;
+  }
+  void remove_from_queue(long long h) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto it = queue_.begin(); it != queue_.end(); ++it)
+      if (it->handle == h) {
+        queue_.erase(it);
+        return;
+      }
+  }
+  void fail_everything(const std::string& why) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& r : queue_) {
+      status_[r.handle].state = -1;
+      status_[r.handle].error = why;
+    }
+    queue_.clear();
+    dead_ = true;
+    cv_.notify_all();
+  }
+
+  void* shm_;
+  int rank_, world_;
+  long long fusion_bytes_;
+  double cycle_ms_;
+  ExecFn exec_;
+  std::vector<char> fusion_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<Request> queue_;
+  std::map<long long, Status> status_;
+  std::map<long long, Request> inflight_;
+  long long next_handle_ = 0;
+  bool stop_requested_ = false, dead_ = false;
+  std::atomic<long long> cycles_{0}, groups_{0};
+};
+
+}  // namespace
+
+PDA_EXPORT void* pda_hvd_create(void* shm, int rank, int world, long long fusion_bytes, double cycle_ms, void* exec) {
+  return new Engine(shm, rank, world, fusion_bytes, cycle_ms, reinterpret_cast<ExecFn>(exec));
+}
+PDA_EXPORT void pda_hvd_shutdown(void* h) { static_cast<Engine*>(h)->shutdown(); }
+PDA_EXPORT void pda_hvd_destroy(void* h) { delete static_cast<Engine*>(h); }
+PDA_EXPORT long long pda_hvd_enqueue(void* h, const char* name, int kind, void* ptr, long long count, int dtype, int op,
+                                     int root, int device, double prescale, double postscale) {
+  return static_cast<Engine*>(h)->enqueue(name, kind, ptr, count, dtype, op, root, device, prescale, postscale);
+}
+PDA_EXPORT int pda_hvd_poll(void* h, long long handle) { return static_cast<Engine*>(h)->poll(handle); }
+PDA_EXPORT int pda_hvd_wait(void* h, long long handle, char* err, int cap) {
+  return static_cast<Engine*>(h)->wait(handle, err, cap);
+}
+PDA_EXPORT void* pda_hvd_request_ptr(void* h, long long handle) { return static_cast<Engine*>(h)->request_ptr(handle); }
+PDA_EXPORT long long pda_hvd_request_count(void* h, long long handle) { return static_cast<Engine*>(h)->request_count(handle); }
+PDA_EXPORT double pda_hvd_request_prescale(void* h, long long handle) { return static_cast<Engine*>(h)->request_prescale(handle); }
+PDA_EXPORT double pda_hvd_request_postscale(void* h, long long handle) { return static_cast<Engine*>(h)->request_postscale(handle); }
+PDA_EXPORT long long pda_hvd_cycles(void* h) { return static_cast<Engine*>(h)->cycles(); }
+PDA_EXPORT long long pda_hvd_fused_groups(void* h) { return static_cast<Engine*>(h)->fused_groups(); }

@@ -1,0 +1,11 @@
+from .sampler import DistributedSampler
+from .datasets import (SyntheticImages, synthetic_cifar10, synthetic_imagenet, synthetic_mnist, CIFAR10Bin, MNISTIdx,
+                       cifar10, mnist, CIFAR10_MEAN, CIFAR10_STD, IMAGENET_MEAN, IMAGENET_STD, MNIST_MEAN, MNIST_STD)
+from .loader import make_loader, DevicePrefetcher, SyntheticDeviceLoader
+
+data_prefetcher = DevicePrefetcher  # the reference's class name
+
+__all__ = ["DistributedSampler", "SyntheticImages", "synthetic_cifar10", "synthetic_imagenet", "synthetic_mnist",
+           "CIFAR10Bin", "MNISTIdx", "cifar10", "mnist", "make_loader", "DevicePrefetcher", "data_prefetcher",
+           "SyntheticDeviceLoader", "CIFAR10_MEAN", "CIFAR10_STD", "IMAGENET_MEAN", "IMAGENET_STD", "MNIST_MEAN",
+           "MNIST_STD"]

@@ -1,0 +1,491 @@
+"""Horovod-compatible collective ops over this package's engine.
+
+API surface used by the reference (/root/reference/5.horovod_distributed.py:70-75,92-125,
+/root/reference/5.2.horovod_pytorch_mnist.py:75-78,115-185) and its semantics:
+
+* ``allreduce(tensor, ...)`` is OUT-OF-PLACE and returns the reduced tensor; ``allreduce_`` is
+  in place.  The default op is Average and the division by ``size()`` happens exactly once.
+* ``*_async`` variants return an integer handle; ``synchronize(handle)`` waits and returns the
+  output; ``poll(handle)`` is non-blocking.
+* requests are matched across ranks by NAME, so ranks may issue them in different orders;
+  un-named requests get ``<op>.noname.<counter>`` like Horovod (then call order must match).
+* ``Compression.fp16`` casts fp32 tensors to fp16 for the wire and back afterwards.
+* ``op=Adasum`` reduces with the adaptive-summation rule instead of the plain sum.
+
+Engines: with one process ``size() == 1`` and everything is a no-op copy; on one host the native
+engine (``csrc/runtime/hvd_core.cc``: background thread, name negotiation over shared memory,
+tensor fusion) runs CPU tensors through the shared-memory backend and device tensors through an
+executor that issues one fused RCCL all-reduce per group; across hosts a synchronous
+``torch.distributed`` path is used.
+"""
+from __future__ import annotations
+
+import atexit
+import ctypes
+import os
+import threading
+from typing import Dict, Optional
+
+import torch
+
+from ..comm import _runtime, discover, RankInfo, TCPStore, PrefixStore
+from ..comm.shm import ShmCommunicator
+from ..ops import multi_tensor as mt
+
+Average, Sum, Adasum, Min, Max, Product = "Average", "Sum", "Adasum", "Min", "Max", "Product"
+_OP_CODE = {Sum: 0, Product: 1, Min: 2, Max: 3, Average: 4}
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3, torch.float64: 4, torch.int32: 5,
+       torch.int64: 6}
+
+_runtime.register({
+    "pda_hvd_create": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
+                                         ctypes.c_double, ctypes.c_void_p]),
+    "pda_hvd_shutdown": (None, [ctypes.c_void_p]),
+    "pda_hvd_destroy": (None, [ctypes.c_void_p]),
+    "pda_hvd_enqueue": (ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_double]),
+    "pda_hvd_poll": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong]),
+    "pda_hvd_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_int]),
+    "pda_hvd_cycles": (ctypes.c_longlong, [ctypes.c_void_p]),
+    "pda_hvd_fused_groups": (ctypes.c_longlong, [ctypes.c_void_p]),
+})
+
+_EXEC_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int,
+                           ctypes.c_int)
+
+
+class HorovodInternalError(RuntimeError):
+    pass
+
+
+class _Compressor:
+    @staticmethod
+    def compress(tensor):
+        return tensor, None
+
+    @staticmethod
+    def decompress(tensor, ctx):
+        return tensor
+
+
+class _FP16Compressor(_Compressor):
+    wire = torch.float16
+
+    @classmethod
+    def compress(cls, tensor):
+        if tensor.dtype.is_floating_point and tensor.dtype != cls.wire:
+            return tensor.to(cls.wire), tensor.dtype
+        return tensor, None
+
+    @staticmethod
+    def decompress(tensor, ctx):
+        return tensor.to(ctx) if ctx is not None else tensor
+
+
+class _BF16Compressor(_FP16Compressor):
+    wire = torch.bfloat16
+
+
+class Compression:
+    """``Compression.none`` / ``Compression.fp16`` (plus bf16, which keeps fp32's range)."""
+    none = _Compressor
+    fp16 = _FP16Compressor
+    bf16 = _BF16Compressor
+
+
+class _Pending:
+    __slots__ = ("eh", "out", "wire", "ctx", "compression", "post", "event", "name", "done")
+
+    def __init__(self):
+        self.eh = None
+        self.done = False
+        self.event = None
+        self.post = 1.0
+
+
+class _State:
+    def __init__(self):
+        self.info: Optional[RankInfo] = None
+        self.initialized = False
+        self.engine = None
+        self.shm = None
+        self.store = None
+        self.lib = None
+        self.exec_cb = None
+        self.handles: Dict[int, _Pending] = {}
+        self.by_engine: Dict[int, _Pending] = {}
+        self.next_handle = 0
+        self.noname = {}
+        self.lock = threading.Lock()
+        self.side_stream = None
+        self.torch_group_ready = False
+        self.multi_host = False
+
+
+_S = _State()
+
+
+# ------------------------------------------------------------------------------- lifecycle
+def init(comm=None, process_sets=None) -> None:
+    """Discover rank/size from the launcher environment and start the engine."""
+    if _S.initialized:
+        return
+    info = discover()
+    _S.info = info
+    _S.initialized = True
+    if info.world_size == 1:
+        return
+    _S.multi_host = info.local_size < info.world_size
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        from ..comm import init_process_group
+        backend = "nccl" if (torch.cuda.is_available() and os.environ.get("HOROVOD_CPU_OPERATIONS", "") != "gloo"
+                             and os.environ.get("PDA_HVD_NO_CUDA", "0") != "1") else "gloo"
+        init_process_group(backend, "env://", info.world_size, info.rank)
+    _S.torch_group_ready = True
+    if _S.multi_host:
+        return
+    # native engine: rendezvous for the shm segment goes through a store of its own
+    from ..comm import native_store
+    base = native_store()
+    if base is None:
+        port = int(os.environ.get("PDA_HVD_PORT", str(info.master_port + 17)))
+        base = TCPStore(info.master_addr, port, info.world_size, is_master=(info.rank == 0))
+        _S.store = base
+    _S.lib = _runtime.lib()
+    _S.shm = ShmCommunicator(PrefixStore("hvd", base), info.rank, info.world_size, name="engine",
+                             slot_bytes=int(os.environ.get("PDA_HVD_SHM_SLOT_BYTES", str(8 << 20))))
+    _S.exec_cb = _EXEC_T(_device_executor)
+    fusion = int(float(os.environ.get("HOROVOD_FUSION_THRESHOLD", str(64 << 20))))
+    cycle = float(os.environ.get("HOROVOD_CYCLE_TIME", "1.0"))
+    _S.engine = _S.lib.pda_hvd_create(_S.shm._h, info.rank, info.world_size, fusion, cycle,
+                                      ctypes.cast(_S.exec_cb, ctypes.c_void_p))
+    atexit.register(shutdown)
+
+
+def shutdown() -> None:
+    if not _S.initialized:
+        return
+    if _S.engine is not None:
+        _S.lib.pda_hvd_shutdown(_S.engine)
+        _S.lib.pda_hvd_destroy(_S.engine)
+        _S.engine = None
+    if _S.shm is not None:
+        _S.shm.close()
+        _S.shm = None
+    if _S.store is not None:
+        _S.store.close()
+        _S.store = None
+    _S.initialized = False
+    _S.handles.clear()
+    _S.by_engine.clear()
+
+
+def _need_init():
+    if not _S.initialized:
+        raise ValueError("Horovod has not been initialized; use hvd.init().")
+
+
+def is_initialized() -> bool:
+    return _S.initialized
+
+
+def size() -> int:
+    _need_init()
+    return _S.info.world_size
+
+
+def rank() -> int:
+    _need_init()
+    return _S.info.rank
+
+
+def local_rank() -> int:
+    _need_init()
+    return _S.info.local_rank
+
+
+def local_size() -> int:
+    _need_init()
+    return _S.info.local_size
+
+
+def cross_rank() -> int:
+    _need_init()
+    return _S.info.node_rank
+
+
+def cross_size() -> int:
+    _need_init()
+    return _S.info.num_nodes
+
+
+def nccl_built() -> bool:
+    """True when device collectives are available (RCCL, reached through the nccl backend)."""
+    import torch.distributed as dist
+    return bool(torch.cuda.is_available() and dist.is_nccl_available())
+
+
+rccl_built = nccl_built
+
+
+def mpi_built() -> bool:
+    return False
+
+
+def gloo_built() -> bool:
+    import torch.distributed as dist
+    return dist.is_gloo_available()
+
+
+def rocm_built() -> bool:
+    return torch.version.hip is not None
+
+
+def cuda_built() -> bool:
+    return False
+
+
+def mpi_threads_supported() -> bool:
+    return False
+
+
+def engine_stats() -> dict:
+    if _S.engine is None:
+        return {"cycles": 0, "fused_groups": 0}
+    return {"cycles": int(_S.lib.pda_hvd_cycles(_S.engine)), "fused_groups": int(_S.lib.pda_hvd_fused_groups(_S.engine))}
+
+
+# ------------------------------------------------------------------------------- helpers
+def _auto_name(kind: str, name: Optional[str]) -> str:
+    if name is not None:
+        return f"{kind}.{name}"
+    with _S.lock:
+        c = _S.noname.get(kind, 0)
+        _S.noname[kind] = c + 1
+    return f"{kind}.noname.{c}"
+
+
+def _resolve_op(average, op):
+    if average is not None and op is not None:
+        raise ValueError("The op parameter supersedes average. Please provide only one of them.")
+    if op is None:
+        op = Sum if average is False else Average
+    if op not in (Average, Sum, Adasum, Min, Max, Product):
+        raise ValueError(f"unknown reduction op {op!r}")
+    return op
+
+
+def _new_handle(p: _Pending) -> int:
+    with _S.lock:
+        _S.next_handle += 1
+        h = _S.next_handle
+        _S.handles[h] = p
+    return h
+
+
+def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
+    """Called from the engine thread with one fused group of device tensors."""
+    try:
+        import torch.distributed as dist
+        ps = [_S.by_engine[int(handles_ptr[i])] for i in range(n)]
+        dev = ps[0].wire.device
+        if _S.side_stream is None:
+            _S.side_stream = torch.cuda.Stream(dev)
+        with torch.cuda.device(dev), torch.cuda.stream(_S.side_stream):
+            for p in ps:
+                if p.event is not None:
+                    _S.side_stream.wait_event(p.event)
+            if kind == 1:
+                for p in ps:
+                    dist.broadcast(p.wire, src=root)
+            else:
+                red = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.PRODUCT, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX,
+                       4: dist.ReduceOp.SUM}[op_code]
+                scale = (1.0 / _S.info.world_size) if op_code == 4 else 1.0
+                if n == 1:
+                    dist.all_reduce(ps[0].wire, op=red)
+                    if scale != 1.0:
+                        ps[0].wire.mul_(scale)
+                else:
+                    wires = [p.wire.view(-1) for p in ps]
+                    flat = mt.flatten(wires)
+                    dist.all_reduce(flat, op=red)
+                    views, off = [], 0
+                    for w in wires:
+                        views.append(flat[off:off + w.numel()])
+                        off += w.numel()
+                    mt.scale(mt.TensorLists([views, wires]), scale)
+            for p in ps:
+                p.event = torch.cuda.Event()
+                p.event.record(_S.side_stream)
+        return 0
+    except Exception as e:  # noqa: BLE001 - must not propagate into the C++ thread
+        import traceback
+        traceback.print_exc()
+        return -1
+
+
+def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: str, root: int, compression,
+            prescale: float, postscale: float) -> int:
+    """Common path: ``out`` receives the result (may alias ``tensor``)."""
+    p = _Pending()
+    p.name, p.out, p.compression = name, out, compression
+    world = _S.info.world_size
+    if out.data_ptr() != tensor.data_ptr():
+        out.copy_(tensor)
+    if world == 1:
+        if prescale * postscale != 1.0 and kind == 0:
+            out.mul_(prescale * postscale)
+        p.done = True
+        return _new_handle(p)
+    if op == Adasum and kind == 0:
+        from .adasum import adasum_allreduce_
+        adasum_allreduce_(out)
+        p.done = True
+        return _new_handle(p)
+    wire, ctx = compression.compress(out)
+    if not wire.is_contiguous():
+        wire = wire.contiguous()
+    p.wire, p.ctx = wire, ctx
+    if wire.dtype not in _DT:
+        raise TypeError(f"hvd: unsupported tensor dtype {wire.dtype}")
+    half = wire.dtype in (torch.float16, torch.bfloat16) or wire.is_cuda
+    if half:  # the engine scales fp32/fp64/int on the CPU only; do the extra factors here otherwise
+        if prescale != 1.0:
+            wire.mul_(prescale)
+        p.post, prescale, postscale = postscale, 1.0, 1.0
+    if _S.engine is None:  # multi-host fallback: synchronous torch.distributed
+        import torch.distributed as dist
+        if kind == 1:
+            dist.broadcast(wire, src=root)
+        else:
+            dist.all_reduce(wire, op={Sum: dist.ReduceOp.SUM, Average: dist.ReduceOp.SUM, Min: dist.ReduceOp.MIN,
+                                      Max: dist.ReduceOp.MAX, Product: dist.ReduceOp.PRODUCT}[op])
+            if op == Average:
+                wire.div_(world)
+        _finish(p)
+        p.done = True
+        return _new_handle(p)
+    if wire.is_cuda:
+        p.event = torch.cuda.Event()
+        p.event.record(torch.cuda.current_stream(wire.device))
+    eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, wire.data_ptr(), wire.numel(), _DT[wire.dtype],
+                                _OP_CODE.get(op, 0), root, 1 if wire.is_cuda else 0, float(prescale), float(postscale))
+    p.eh = int(eh)
+    with _S.lock:
+        _S.by_engine[p.eh] = p
+    return _new_handle(p)
+
+
+def _finish(p: _Pending) -> None:
+    if p.post != 1.0:
+        p.wire.mul_(p.post)
+    res = p.compression.decompress(p.wire, p.ctx)
+    if res.data_ptr() != p.out.data_ptr():
+        p.out.copy_(res.view_as(p.out))
+
+
+def synchronize(handle: int) -> torch.Tensor:
+    p = _S.handles.pop(handle, None)
+    if p is None:
+        raise ValueError(f"unknown or already synchronized handle {handle}")
+    if not p.done:
+        err = ctypes.create_string_buffer(512)
+        rc = _S.lib.pda_hvd_wait(_S.engine, p.eh, err, 512)
+        with _S.lock:
+            _S.by_engine.pop(p.eh, None)
+        if rc != 0:
+            raise HorovodInternalError(err.value.decode() or "collective failed")
+        if p.wire.is_cuda and p.event is not None:
+            torch.cuda.current_stream(p.wire.device).wait_event(p.event)
+        _finish(p)
+    return p.out
+
+
+def poll(handle: int) -> bool:
+    p = _S.handles.get(handle)
+    if p is None:
+        raise ValueError(f"unknown handle {handle}")
+    return True if p.done else _S.lib.pda_hvd_poll(_S.engine, p.eh) != 0
+
+
+# ------------------------------------------------------------------------------- collectives
+def allreduce_async(tensor, average=None, name=None, op=None, prescale_factor=1.0, postscale_factor=1.0,
+                    compression=Compression.none, process_set=None) -> int:
+    _need_init()
+    op = _resolve_op(average, op)
+    return _submit(0, tensor, torch.empty_like(tensor), _auto_name("allreduce", name), op, 0, compression,
+                   prescale_factor, postscale_factor)
+
+
+def allreduce_async_(tensor, average=None, name=None, op=None, prescale_factor=1.0, postscale_factor=1.0,
+                     compression=Compression.none, process_set=None) -> int:
+    _need_init()
+    op = _resolve_op(average, op)
+    return _submit(0, tensor, tensor, _auto_name("allreduce", name), op, 0, compression, prescale_factor,
+                   postscale_factor)
+
+
+def allreduce(tensor, average=None, name=None, compression=Compression.none, op=None, prescale_factor=1.0,
+              postscale_factor=1.0, process_set=None) -> torch.Tensor:
+    """Out-of-place: returns the reduced tensor, leaves ``tensor`` untouched."""
+    return synchronize(allreduce_async(tensor, average, name, op, prescale_factor, postscale_factor, compression))
+
+
+def allreduce_(tensor, average=None, name=None, op=None, prescale_factor=1.0, postscale_factor=1.0,
+               compression=Compression.none, process_set=None) -> torch.Tensor:
+    return synchronize(allreduce_async_(tensor, average, name, op, prescale_factor, postscale_factor, compression))
+
+
+def grouped_allreduce(tensors, average=None, name=None, compression=Compression.none, op=None):
+    hs = [allreduce_async(t, average, None if name is None else f"{name}.{i}", op, compression=compression)
+          for i, t in enumerate(tensors)]
+    return [synchronize(h) for h in hs]
+
+
+def broadcast_async(tensor, root_rank, name=None, process_set=None) -> int:
+    _need_init()
+    return _submit(1, tensor, tensor.clone(), _auto_name("broadcast", name), Sum, root_rank, Compression.none, 1.0, 1.0)
+
+
+def broadcast_async_(tensor, root_rank, name=None, process_set=None) -> int:
+    _need_init()
+    return _submit(1, tensor, tensor, _auto_name("broadcast", name), Sum, root_rank, Compression.none, 1.0, 1.0)
+
+
+def broadcast(tensor, root_rank, name=None, process_set=None) -> torch.Tensor:
+    return synchronize(broadcast_async(tensor, root_rank, name))
+
+
+def broadcast_(tensor, root_rank, name=None, process_set=None) -> torch.Tensor:
+    return synchronize(broadcast_async_(tensor, root_rank, name))
+
+
+def allgather(tensor, name=None, process_set=None) -> torch.Tensor:
+    """Concatenate every rank's tensor along dim 0 (equal shapes across ranks)."""
+    _need_init()
+    world = _S.info.world_size
+    if world == 1:
+        return tensor.clone()
+    t = tensor.contiguous()
+    if t.dim() == 0:
+        t = t.reshape(1)
+    # every rank fills its own slice of a zero buffer and the slices are summed: this rides on the
+    # name-negotiated all-reduce path, so it is safe next to in-flight asynchronous requests
+    out = torch.zeros((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    out[_S.info.rank].copy_(t)
+    allreduce_(out, name=None if name is None else f"allgather.{name}", op=Sum)
+    return out.reshape((world * t.shape[0],) + tuple(t.shape[1:]))
+
+
+def barrier(process_set=None) -> None:
+    _need_init()
+    if _S.info.world_size > 1:
+        allreduce_(torch.zeros(1), name=None, op=Sum)
+
+
+def join(device: int = -1) -> int:
+    barrier()
+    return -1

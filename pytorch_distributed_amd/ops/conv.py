@@ -136,6 +136,27 @@ def direct_conv(mode: int, a: torch.Tensor, b: torch.Tensor, bias, out: torch.Te
                                  _lib.stream()), "pda_direct_conv")
 
 
+def grad_sink(weight: torch.Tensor):
+    """KRSC fp32 view of ``weight.grad`` that wgrad may accumulate into directly, or None.
+
+    Opt-in per parameter (``_pda_direct_grad``, set by this package's DDP wrapper and fused
+    optimizer): it skips the zero-fill + AccumulateGrad add per conv, but bypasses autograd's own
+    gradient hooks, so ``_pda_grad_ready`` (if present) is called instead."""
+    if not getattr(weight, "_pda_direct_grad", False):
+        return None
+    g = weight.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or g.shape != weight.shape:
+        return None
+    v = g.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else None
+
+
+def notify_grad_ready(weight: torch.Tensor) -> None:
+    cb = getattr(weight, "_pda_grad_ready", None)
+    if cb is not None:
+        cb()
+
+
 # --------------------------------------------------------------------------- weight caches
 class WeightCache:
     """Low-precision KRSC copy and CRSK transpose of one fp32 master weight, refreshed
@@ -221,11 +242,15 @@ class _Conv2dFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 direct_conv(1, dy, ctx.w_lp, None, dx, dims, stride, pad)
         if ctx.needs_input_grad[1]:
-            dwk = wgrad_gpu(dy, x, R, S, stride, pad) if ctx.used_igemm else None
+            sink = grad_sink(weight)
+            dwk = wgrad_gpu(dy, x, R, S, stride, pad, out=sink) if ctx.used_igemm else None
             if dwk is None:
-                dwk = torch.zeros((K, R, S, C), device=dy.device, dtype=torch.float32)
+                dwk = sink if sink is not None else torch.zeros((K, R, S, C), device=dy.device, dtype=torch.float32)
                 direct_conv(2, dy, x, None, dwk, dims, stride, pad)
-            dw = dwk.permute(0, 3, 1, 2).to(weight.dtype)
+            if sink is not None:
+                notify_grad_ready(weight)
+            else:
+                dw = dwk.permute(0, 3, 1, 2).to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             l = _lib.lib()
             db = torch.empty(K, device=dy.device, dtype=torch.float32)

@@ -76,12 +76,16 @@ class _ConvBnActFn(torch.autograd.Function):
                 C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
                               (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
         if ctx.needs_input_grad[1]:
-            dwk = C.wgrad_gpu(dy, x, R, S, stride, pad)
+            sink = C.grad_sink(weight)
+            dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink)
             if dwk is None:
                 raise RuntimeError("conv_bn_act: wgrad shape not supported")
-            dw = dwk.permute(0, 3, 1, 2)
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
+            if sink is not None:
+                C.notify_grad_ready(weight)   # accumulated in place: nothing for autograd to add
+            else:
+                dw = dwk.permute(0, 3, 1, 2)
+                if dw.dtype != weight.dtype:
+                    dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
         return dx, dw, dg, db, dres, None, None, None, None, None

@@ -39,6 +39,10 @@ class FusedSGD(Optimizer):
         self._lists: Dict[int, tuple] = {}
         self._amp_scaler = None          # set by amp.initialize
         self._model_copies: Dict[int, torch.Tensor] = {}  # id(param) -> half copy updated in-kernel
+        for g in self.param_groups:
+            for p in g["params"]:
+                # let this package's conv ops accumulate weight gradients straight into an existing .grad
+                p._pda_direct_grad = True
 
     # -- mixed precision hooks -------------------------------------------------------------
     def attach_scaler(self, scaler) -> None:
