@@ -273,19 +273,37 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
       accum(vd, vy, vo);
     }
   }
+  // Row lanes that share a channel vector sit VT lanes apart: fold them inside the wave with
+  // shuffles first (VT is a power of two), so only <= 4 values per vector cross LDS.
+  if (g.VT < 64) {
+    for (int o = g.VT; o < 64; o <<= 1) {
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    red[0][threadIdx.x * EPC + e] = dg[e];
-    red[1][threadIdx.x * EPC + e] = db[e];
+      for (int e = 0; e < EPC; ++e) {
+        dg[e] += __shfl_xor(dg[e], o, 64);
+        db[e] += __shfl_xor(db[e], o, 64);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (g.VT >= 64 || lane < g.VT) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[0][(wave * 64 + lane) * EPC + e] = dg[e];
+      red[1][(wave * 64 + lane) * EPC + e] = db[e];
+    }
   }
   __syncthreads();
   if (g.rl == 0 && g.vec < vpr) {
+    const int v = threadIdx.x;               // == vector index inside this block's VT
+    const int nent = g.VT < 64 ? 4 : g.RS;   // partial sums per vector left in LDS
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float a = 0.f, b = 0.f;
-      for (int k = 0; k < g.RS; ++k) {
-        a += red[0][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
-        b += red[1][(k * g.VT + (threadIdx.x % g.VT)) * EPC + e];
+      for (int k = 0; k < nent; ++k) {
+        const int w = g.VT < 64 ? k : (v + k * g.VT) >> 6;
+        const int l = g.VT < 64 ? v : (v & 63);
+        a += red[0][(w * 64 + l) * EPC + e];
+        b += red[1][(w * 64 + l) * EPC + e];
       }
       pdg[(long long)blockIdx.x * C + g.vec * EPC + e] = a;
       pdb[(long long)blockIdx.x * C + g.vec * EPC + e] = b;

@@ -46,10 +46,11 @@ class BasicBlock(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
-        out = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True)
+        # `identity` is an alias of x handed back by conv1's op, so the gradient of the skip branch
+        # is added inside conv1's dgrad epilogue rather than by a separate kernel
+        out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True)
         if self.downsample is not None:
-            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], x, relu=False)
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
         return pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, residual=identity)
 
 
@@ -69,11 +70,10 @@ class Bottleneck(tnn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
-        out = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True)
+        out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True)
         out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
-            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], x, relu=False)
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
         return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity)
 
 

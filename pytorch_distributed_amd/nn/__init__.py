@@ -110,11 +110,12 @@ class ConvBnAct(tnn.Module):
 
     @staticmethod
     def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
-            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+            residual: Optional[torch.Tensor] = None, passthrough: bool = False):
         if conv.bias is not None:
-            return bn(conv(x), residual, relu)
+            o = bn(conv(x), residual, relu)
+            return (o, x) if passthrough else o
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
-                               bn.state(), conv._cache)
+                               bn.state(), conv._cache, passthrough)
 
 
 class ReLU(tnn.Module):

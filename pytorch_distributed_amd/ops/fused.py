@@ -26,7 +26,7 @@ from . import _lib, conv as C, norm as Nm, pool as P
 class _ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
-                cache: C.WeightCache):
+                cache: C.WeightCache, passthrough: bool = False):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -52,10 +52,14 @@ class _ConvBnActFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
         mask_src = out if (relu and (residual is not None or not train_stats)) else None
         ctx.save_for_backward(x, weight, y if train_stats else None, mask_src, mean, invstd, scale, shift, gamma)
+        if passthrough:
+            # second output = alias of the input: whatever consumes it (the block's identity branch)
+            # sends its gradient back through THIS node, where the dgrad epilogue adds it for free
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dalias=None):
         x, weight, y, mask_src, mean, invstd, scale, shift, gamma = ctx.saved_tensors
         stride, pad, relu, has_res, count, group, cache, train_stats = ctx.cfg
         dout = dout.contiguous()
@@ -70,11 +74,18 @@ class _ConvBnActFn(torch.autograd.Function):
             dg = db = None
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad)
+            if dalias is not None:
+                dalias = dalias.contiguous()
+            dx = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
+                             res=dalias)
             if dx is None:
                 dx = torch.empty_like(x)
                 C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
                               (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
+                if dalias is not None:
+                    dx = dx + dalias
+        elif dalias is not None:
+            dx = dalias
         if ctx.needs_input_grad[1]:
             sink = C.grad_sink(weight)
             dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink)
@@ -88,17 +99,22 @@ class _ConvBnActFn(torch.autograd.Function):
                     dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-        return dx, dw, dg, db, dres, None, None, None, None, None
+        return dx, dw, dg, db, dres, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
-                cache: Optional[C.WeightCache] = None):
-    """NHWC fused conv + BatchNorm (+residual) (+ReLU)."""
+                cache: Optional[C.WeightCache] = None, passthrough: bool = False):
+    """NHWC fused conv + BatchNorm (+residual) (+ReLU).
+
+    ``passthrough=True`` returns ``(out, x_alias)``: feed ``x_alias`` to the other consumer of ``x``
+    (the residual branch of a ResNet block) and its gradient is summed inside this op's dgrad
+    epilogue instead of by a separate element-wise add."""
     if not x.is_cuda:
         y = C.conv2d_ref(x, weight, None, stride, pad)
-        return Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
+        o = Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
+        return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
-                              cache or C.WeightCache())
+                              cache or C.WeightCache(), passthrough)
 
 
 # ------------------------------------------------------------------------------------ stem

@@ -1,0 +1,148 @@
+"""Worker bodies for the multi-process CPU tests (spawned with pytorch_distributed_amd.launch.spawn)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port, method="tcp"):
+    from pytorch_distributed_amd import comm
+    url = f"tcp://127.0.0.1:{port}" if method == "tcp" else f"file://{port}"
+    comm.init_process_group("gloo", url, world_size=world, rank=rank)
+    return comm
+
+
+def ddp_equivalence(rank, world, port, wire_fp16):
+    import torch.distributed as dist
+    comm = _init(rank, world, port)
+    from pytorch_distributed_amd import models, ops
+    from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
+    torch.manual_seed(rank)                       # replicas start different: the ctor must broadcast rank 0's
+    ddp = DDP(models.resnet18(num_classes=10), bucket_cap_mb=4, first_bucket_mb=0.1,
+              wire_dtype=torch.bfloat16 if wire_fp16 else None)
+    ref = models.resnet18(num_classes=10)
+    ref.load_state_dict({k: v.clone() for k, v in ddp.module.state_dict().items()})
+    torch.manual_seed(100)
+    X, T = torch.randn(4 * world, 3, 32, 32), torch.randint(0, 10, (4 * world,))
+    x, t = X[rank * 4:(rank + 1) * 4], T[rank * 4:(rank + 1) * 4]
+    nb0 = None
+    for it in range(3):
+        ddp.zero_grad()
+        ops.cross_entropy(ddp(x), t).backward()
+        grads = []
+        for r in range(world):
+            ref.zero_grad()
+            ops.cross_entropy(ref(X[r * 4:(r + 1) * 4]), T[r * 4:(r + 1) * 4]).backward()
+            grads.append([p.grad.clone() for p in ref.parameters()])
+        avg = [sum(g[i] for g in grads) / world for i in range(len(grads[0]))]
+        err = max((a - p.grad).abs().max().item() / (a.abs().max().item() + 1e-9)
+                  for a, p in zip(avg, ddp.module.parameters()))
+        assert err < (2e-2 if wire_fp16 else 1e-4), (it, err)
+        if it == 0:
+            nb0 = len(ddp.bucket_summary())
+    assert len(ddp.bucket_summary()) >= 3 and nb0 >= 3
+    assert all(k.startswith("module.") for k in ddp.state_dict())
+    # no_sync accumulates locally, the next synced backward reduces the sum
+    ddp.zero_grad()
+    with ddp.no_sync():
+        ops.cross_entropy(ddp(x), t).backward()
+    local = [p.grad.clone() for p in ddp.module.parameters()]
+    ops.cross_entropy(ddp(x), t).backward()
+    chk = ddp.module.fc.bias.grad.clone()
+    g = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(g, chk)
+    assert all(torch.allclose(g[0], gi, atol=1e-6) for gi in g), "grads must be identical after sync"
+    assert not torch.allclose(local[-1], chk)
+    comm.destroy_process_group()
+
+
+def apex_flavour(rank, world, port):
+    comm = _init(rank, world, port)
+    from pytorch_distributed_amd.parallel import ApexDistributedDataParallel
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    ddp = ApexDistributedDataParallel(m, message_size=64, delay_allreduce=(rank >= 0 and False))
+    x = torch.full((2, 8), float(rank + 1))
+    ddp(x).sum().backward()
+    import torch.distributed as dist
+    g = ddp.module[2].bias.grad.clone()
+    gs = [torch.zeros_like(g) for _ in range(world)]
+    dist.all_gather(gs, g)
+    assert all(torch.allclose(gs[0], gi) for gi in gs)
+    comm.destroy_process_group()
+
+
+def syncbn_equivalence(rank, world, port):
+    comm = _init(rank, world, port)
+    from pytorch_distributed_amd import nn as pnn
+    torch.manual_seed(0)
+    full = torch.randn(4 * world, 5, 5, 8)
+    bn = pnn.SyncBatchNorm(8)
+    ref = torch.nn.BatchNorm2d(8)
+    x = full[rank * 4:(rank + 1) * 4].clone().requires_grad_(True)
+    xf = full.clone().requires_grad_(True)
+    out = bn(x, None, True)
+    o = torch.relu(ref(xf.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    assert torch.allclose(out, o[rank * 4:(rank + 1) * 4], atol=1e-5)
+    w = torch.linspace(0.5, 1.5, out.numel()).view_as(out)
+    wf = torch.cat([w] * world) if False else None
+    (out * w).sum().backward()
+    wfull = torch.zeros_like(o)
+    for r in range(world):
+        wfull[r * 4:(r + 1) * 4] = w
+    (o * wfull).sum().backward()
+    assert torch.allclose(x.grad, xf.grad[rank * 4:(rank + 1) * 4], atol=1e-4)
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, atol=1e-4)
+    comm.destroy_process_group()
+
+
+def shm_collectives(rank, world, port):
+    from pytorch_distributed_amd.comm import TCPStore
+    from pytorch_distributed_amd.comm.shm import ShmCommunicator, SUM, MAX, AVG
+    store = TCPStore("127.0.0.1", port, world, is_master=(rank == 0))
+    c = ShmCommunicator(store, rank, world, slot_bytes=4096)       # tiny slots: exercises chunking
+    for dt in (torch.float32, torch.float64, torch.float16, torch.bfloat16, torch.int64, torch.int32):
+        t = (torch.arange(3000) % 7 + rank).to(dt)
+        c.all_reduce(t, SUM)
+        exp = (torch.arange(3000) % 7).double() * world + sum(range(world))
+        assert torch.allclose(t.double(), exp, rtol=2e-2), dt
+    t = torch.full((10,), float(rank))
+    c.all_reduce(t, MAX)
+    assert t[0] == world - 1
+    t = torch.full((10,), float(rank))
+    w = c.all_reduce(t, AVG, async_op=True)
+    w.wait()
+    assert torch.allclose(t, torch.full((10,), (world - 1) / 2))
+    b = torch.arange(5000.0) if rank == 1 else torch.zeros(5000)
+    c.broadcast(b, src=1)
+    assert torch.equal(b, torch.arange(5000.0))
+    out = torch.empty(world * 3)
+    c.all_gather(out, torch.full((3,), float(rank)))
+    assert out.view(world, 3)[:, 0].tolist() == [float(r) for r in range(world)]
+    got = c.all_gather_bytes(b"x" * (rank + 1))
+    assert [len(g) for g in got] == list(range(1, world + 1))
+    c.barrier()
+    c.close()
+    store.close()
+
+
+def file_rendezvous(rank, world, path):
+    import torch.distributed as dist
+    comm = _init(rank, world, path, method="file")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    assert t.item() == sum(range(world))
+    assert comm.native_store() is not None and comm.native_store().num_keys() > 0
+    comm.destroy_process_group()
+
+
+def crasher(rank, marker):
+    import time
+    if rank == 1:
+        raise ValueError("boom from rank 1")
+    time.sleep(60)
+    open(marker, "w").write("survived")
