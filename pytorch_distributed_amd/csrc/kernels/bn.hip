@@ -414,9 +414,18 @@ static inline int col_blocks_y(int C, int es) {
     default: return -6;                             \
   }
 
-// Number of row-partials a reduce over M rows will produce (python allocates [n][C]).
-PDA_EXPORT int pda_bn_num_partials(long long M) {
-  long long n = (M + 255) / 256;
+// Number of row-partials (= workgroups along M) a column reduce over [M][C] will produce; python
+// allocates [n][C].  A block covers RS = 256/VT rows per pass (VT = channel vectors per block), so
+// wide, short tensors (late ResNet stages: M small, C = 2048) still get ~1024 workgroups with at
+// least four passes each instead of a handful of long serial loops.
+PDA_EXPORT int pda_bn_num_partials(long long M, int C, int dtype) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  const int vpr = C / (16 / es);
+  int vt = vpr < 256 ? vpr : 256;
+  int p = 1;
+  while (p * 2 <= vt) p *= 2;
+  const long long rs = 256 / p;
+  long long n = (M + 4 * rs - 1) / (4 * rs);
   if (n > 1024) n = 1024;
   if (n < 1) n = 1;
   return (int)n;
@@ -426,7 +435,7 @@ PDA_EXPORT int pda_bn_stats_partial(int dtype, const void* y, long long M, int C
                                     hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0 || ((uintptr_t)y & 15)) return -1;
-  const int nb = pda_bn_num_partials(M);
+  const int nb = pda_bn_num_partials(M, C, dtype);
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256),
                                            0, st, (const T*)y, M, C, psum, psq));
   return pda_check_launch();
@@ -487,7 +496,7 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
                                  int relu, float* pdg, float* pdb, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0) return -1;
-  const int nb = pda_bn_num_partials(M);
+  const int nb = pda_bn_num_partials(M, C, dtype);
   PDA_DISPATCH_T(dtype,
                  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256), 0, st,
                                     (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift, M, C,

@@ -73,7 +73,10 @@ igemm_kernel(ConvArgs a) {
   constexpr int MI = WTM / 32, NI = WTN / 32;
   static_assert(MI >= 1 && NI >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * ROWB];
+  // operand tiles (two stages); the 16-bit epilogue re-uses the space to stage the output tile
+  constexpr int TILE_BYTES = 2 * (BM + BN) * ROWB;
+  constexpr int EPI_BYTES = sizeof(T) == 2 ? BM * (BN * (int)sizeof(T) + 16) : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES];
   unsigned char* ldsA = lds;
   unsigned char* ldsB = lds + 2 * BM * ROWB;
 
@@ -262,30 +265,81 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < NI; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 
+  // 16-bit types with a vector-friendly Co: stage the tile through LDS so the global
+  // stores (and the residual loads) are whole 16-byte vectors, 16 lanes per 256-byte row
+  // segment, instead of 2-byte accesses scattered over 64-byte pieces.
+  const bool vec_epi = (sizeof(T) == 2) && (a.Co % EPC == 0);
+  if (vec_epi) {
+    constexpr int CP = BN * (int)sizeof(T) + 16;  // padded row pitch, keeps 16-byte alignment
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * WTN + j * 32 + l31;
+      for (int j = 0; j < NI; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-        float v = acc[i][j][g];
-        const bool ok = (m < a.M) && (n < a.Co);
-        const long long o = (long long)m * a.Co + n;
-        if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
-        if (a.relu) v = fmaxf(v, 0.f);
-        const T tv = ElemTraits<T>::from_f32(v);
-        if (ok) Y[o] = tv;
-        if (stats) {
-          // statistics of the value as stored, so mean/var describe the tensor
-          // that the normalisation pass will read back
-          const float fv = ok ? ElemTraits<T>::to_f32(tv) : 0.f;
-          csum[j] += fv;
-          csq[j] += fv * fv;
+        for (int g = 0; g < 16; ++g) {
+          const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          const T tv = ElemTraits<T>::from_f32(acc[i][j][g]);
+          *reinterpret_cast<T*>(lds + row * CP + col * (int)sizeof(T)) = tv;
+          if (stats) {
+            // rows past M come from all-zero A rows, so they add nothing
+            const float fv = ElemTraits<T>::to_f32(tv);
+            csum[j] += fv;
+            csq[j] += fv * fv;
+          }
         }
       }
+    __syncthreads();
+    constexpr int VPR = BN / EPC;  // vectors per tile row
+#pragma unroll
+    for (int k = 0; k < BM * VPR / 256; ++k) {
+      const int v = t + 256 * k;
+      const int row = v / VPR, cv = v % VPR;
+      const int m = m0 + row, n = n0 + cv * EPC;
+      if (m < a.M && n < a.Co) {
+        Vec16<T> val = *reinterpret_cast<const Vec16<T>*>(lds + row * CP + cv * 16);
+        const long long o = (long long)m * a.Co + n;
+        if (Rz != nullptr) {
+          const Vec16<T> rv = load16(Rz + o);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + ElemTraits<T>::to_f32(rv.v[e]));
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            val.v[e] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(val.v[e]), 0.f));
+        }
+        store16(Y + o, val);
+      }
     }
+    if (stats) __syncthreads();  // the statistics scratch below reuses the staging area
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          float v = acc[i][j][g];
+          const bool ok = (m < a.M) && (n < a.Co);
+          const long long o = (long long)m * a.Co + n;
+          if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
+          if (a.relu) v = fmaxf(v, 0.f);
+          const T tv = ElemTraits<T>::from_f32(v);
+          if (ok) Y[o] = tv;
+          if (stats) {
+            // statistics of the value as stored, so mean/var describe the tensor
+            // that the normalisation pass will read back
+            const float fv = ok ? ElemTraits<T>::to_f32(tv) : 0.f;
+            csum[j] += fv;
+            csq[j] += fv * fv;
+          }
+        }
+      }
+  }
 
   if (stats) {
     float* sred = reinterpret_cast<float*>(lds);  // [2 wm][BN][2]; tiles are dead after the last barrier

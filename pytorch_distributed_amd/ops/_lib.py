@@ -35,7 +35,7 @@ _SIGS = {
     "pda_krsc_to_crsk": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "pda_direct_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                         c_i, c_i, c_p],
-    "pda_bn_num_partials": [c_ll],
+    "pda_bn_num_partials": [c_ll, c_i, c_i],
     "pda_bn_stats_partial": [c_i, c_p, c_ll, c_i, c_p, c_p, c_p],
     "pda_bn_reduce_partials": [c_p, c_p, c_i, c_i, c_p, c_p],
     "pda_bn_finalize": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],

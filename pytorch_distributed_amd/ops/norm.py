@@ -44,7 +44,7 @@ def stats_partials(y2d: torch.Tensor):
     """Per-row-block column sums of y[M][C] -> (psum, psq) each [nparts][C] fp32."""
     l = _lib.lib()
     M, C = y2d.shape
-    n = l.pda_bn_num_partials(M)
+    n = l.pda_bn_num_partials(M, C, _lib.dt(y2d))
     part = torch.empty((2, n, C), device=y2d.device, dtype=torch.float32)
     _lib.check(l.pda_bn_stats_partial(_lib.dt(y2d), y2d.data_ptr(), M, C, part[0].data_ptr(), part[1].data_ptr(),
                                       _lib.stream()), "pda_bn_stats_partial")
@@ -110,7 +110,7 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     C = y.shape[-1]
     M = y.numel() // C
     dev = y.device
-    n = l.pda_bn_num_partials(M)
+    n = l.pda_bn_num_partials(M, C, _lib.dt(y))
     part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
     _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
                                    invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C, int(relu),

@@ -362,7 +362,7 @@ def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw, batch):
     allr = torch.cat([gr[k].grad.float().flatten() for k in g])
     total = _cos(allg, allr)
     median = cos[len(cos) // 2][0]
-    lim_total, lim_med = {torch.float32: (0.9999, 0.9999), torch.float16: (0.99, 0.99),
+    lim_total, lim_med = {torch.float32: (0.9999, 0.9999), torch.float16: (0.98, 0.98),
                           torch.bfloat16: (0.90, 0.93)}[dtype]
     assert total > lim_total and median > lim_med, (total, median, cos[:3])
     rs, rr = dict(m.named_buffers()), dict(ref.named_buffers())
