@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Launch style 4 - mixed precision + DDP.  Counterpart of /root/reference/4.apex_distributed2.py
+(and of the side-stream ``data_prefetcher`` of /root/reference/4.apex_distributed.py, which ``engine.fit``
+uses on GPUs without the upstream double normalisation):
+
+    python -m pytorch_distributed_amd.launch --nproc_per_node=4 --use_argv_local_rank 4_amp_distributed.py
+
+``amp.initialize(model, optimizer)`` (O1 by default, dynamic loss scale 2**16) then the
+apex-flavoured DDP (flat arrival-order buckets); the step is
+``with amp.scale_loss(loss, optimizer) as scaled: scaled.backward(); optimizer.step()``."""
+import _common  # noqa: F401
+import torch
+
+from pytorch_distributed_amd import amp, comm, engine, utils
+from pytorch_distributed_amd.parallel import ApexDistributedDataParallel
+
+
+def main():
+    parser = engine.build_parser("AMP + DDP training", epochs=10, local_rank_flag=True)
+    parser.set_defaults(precision="fp16")
+    args = parser.parse_args()
+    utils.seed_everything(args.seed)
+    use_cuda = torch.cuda.is_available() and not args.cpu
+    info = comm.init_process_group("nccl" if use_cuda else "gloo", "env://")
+    local_rank = info.local_rank if args.local_rank < 0 else args.local_rank
+    device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    model = engine.make_model(args, device)
+    optimizer = engine.make_optimizer(args, model)
+    level = args.opt_level or "O1"
+    dtype = torch.bfloat16 if (args.precision == "bf16" or not use_cuda) else torch.float16
+    model, optimizer = amp.initialize(model, optimizer, opt_level=level, dtype=dtype)
+    model = ApexDistributedDataParallel(model)
+    train_set, val_set = engine.make_datasets(args)
+    engine.fit(args, model, optimizer, device, train_set, val_set, int(args.batch_size / info.world_size),
+               distributed=True, zero_grad=model.zero_grad)
+    comm.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
