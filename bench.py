@@ -143,7 +143,7 @@ def main():
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
                        "weights": "random-init", "final_loss": round(final_loss, 4),
-                       "baseline_note": "reference publishes no number (BASELINE.md); vs_baseline is null"},
+                       "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

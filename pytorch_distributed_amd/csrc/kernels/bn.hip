@@ -1,6 +1,6 @@
 // BatchNorm (training + eval) for NHWC activations viewed as [M][C], with the
 // ReLU and residual-add of a ResNet block fused into the same passes
-// (SURVEY K6-K9; reference trigger: torchvision's BatchNorm2d/ReLU inside
+// (reference trigger: torchvision's BatchNorm2d/ReLU inside
 // `model(images)`, /root/reference/2.distributed.py:213).
 //
 // Forward (train):  statistics are per-tile partial sums (written either by the
@@ -127,13 +127,15 @@ bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                   long long* __restrict__ num_batches_tracked) {
   __shared__ double red[2][64][17];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int pl = threadIdx.x >> 4;
   double s, q;
   reduce_partials_16x64(psum, psq, nparts, C, c, pl, s, q, red);
   if (pl != 0 || c >= C) return;
+  if (num_batches_tracked && c == 0) num_batches_tracked[0] += 1;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -377,7 +379,7 @@ bn_bwd_finalize_kernel(const float* __restrict__ pdg, const float* __restrict__ 
                        float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ mean,
                        const float* __restrict__ invstd, const float* __restrict__ scale,
                        const float* __restrict__ shift, const float* __restrict__ gamma, float inv_count,
-                       float* __restrict__ coef) {
+                       float* __restrict__ coef, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
   __shared__ double red[2][64][17];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15);
   const int pl = threadIdx.x >> 4;
@@ -386,6 +388,9 @@ bn_bwd_finalize_kernel(const float* __restrict__ pdg, const float* __restrict__ 
   if (pl != 0 || c >= C) return;
   dgamma[c] = (float)a;
   dbeta[c] = (float)b;
+  // parameter gradients accumulated straight into the optimizer's / reducer's buffers
+  if (acc_dgamma) acc_dgamma[c] += (float)a;
+  if (acc_dbeta) acc_dbeta[c] += (float)b;
   if (coef) bwd_coefs(c, C, (float)a, (float)b, mean, invstd, scale, shift, gamma, inv_count, coef);
 }
 
@@ -451,10 +456,10 @@ PDA_EXPORT int pda_bn_reduce_partials(const float* psum, const float* psq, int n
 PDA_EXPORT int pda_bn_finalize(const float* psum, const float* psq, int nparts, int C, double count, float eps,
                                float momentum, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                               float* shift_out, hipStream_t st) {
+                               float* shift_out, long long* num_batches_tracked, hipStream_t st) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
                      eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
-                     shift_out);
+                     shift_out, num_batches_tracked);
   return pda_check_launch();
 }
 
@@ -508,9 +513,9 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
 PDA_EXPORT int pda_bn_bwd_finalize(const float* pdg, const float* pdb, int nparts, int C, float* dgamma,
                                    float* dbeta, const float* mean, const float* invstd, const float* scale,
                                    const float* shift, const float* gamma, double count, float* coef,
-                                   hipStream_t st) {
+                                   float* acc_dgamma, float* acc_dbeta, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, pdg, pdb, nparts, C, dgamma,
-                     dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef);
+                     dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma, acc_dbeta);
   return pda_check_launch();
 }
 

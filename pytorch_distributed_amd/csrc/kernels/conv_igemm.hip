@@ -1,7 +1,7 @@
 // Implicit-GEMM convolution for gfx950 on MFMA: forward (fprop), input gradient
 // (dgrad) and weight gradient (wgrad), NHWC activations, fp16 / bf16 / fp32.
 //
-// GEMM view (SURVEY K1-K5; reference trigger: the `model(images)` /
+// GEMM view (reference trigger: the `model(images)` /
 // `loss.backward()` calls, /root/reference/2.distributed.py:213,231, which land
 // in cuDNN there):
 //   fprop : Y[m][n]  = sum_k A[m][k] * Wk[n][k]      m=(img,ho,wo) n=cout k=(r,s,cin)
@@ -34,9 +34,18 @@ struct ConvArgs {
   int R, S;
   int stride_h, stride_w, pad_h, pad_w;
   int sh_log2, sw_log2;  // dgrad only (power-of-two strides)
-  int M;
+  int M;                 // GEMM rows (per parity class in the stride-2 dgrad mode)
   int relu;
+  int Ha, Wb;            // stride-2 dgrad: pixels per parity class along h / w
 };
+
+// MODE 0: fprop.  MODE 1: dgrad, any power-of-two stride: every tap is visited and rows whose tap
+// does not land on an output pixel of the forward conv load zeros.  MODE 2: dgrad for stride 2,
+// split by the parity (h&1, w&1) of the input-gradient pixel: a pixel of one parity class only ever
+// receives the taps r = (h+pad) mod 2, +2, ... (likewise s), so each class is its own small
+// stride-1 GEMM over dY with 1/4 of the taps on average and no zero rows; one launch runs the
+// four classes back to back, heaviest first.
+enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_DGRAD_S2 = 2 };
 
 template <typename T> struct Mfma32;
 template <> struct Mfma32<f16> {
@@ -60,9 +69,11 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
   return (row / RPB) & (CPR - 1);
 }
 
-template <typename T, int BM, int BN, int ROWB, bool DGRAD>
+template <typename T, int BM, int BN, int ROWB, int MODE>
 __global__ void __launch_bounds__(256)
 igemm_kernel(ConvArgs a) {
+  constexpr bool DGRAD = MODE != MODE_FPROP;
+  constexpr bool PAR = MODE == MODE_DGRAD_S2;
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
   constexpr int BK = ROWB / sizeof(T);     // K elements per step
   constexpr int CPR = ROWB / 16;           // chunks per tile row
@@ -87,7 +98,15 @@ igemm_kernel(ConvArgs a) {
 
   const int tiles_n = (a.Co + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
-  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int ph = 0, pw = 0;
+  if (PAR) {
+    const int per = tiles_m * tiles_n;
+    const int q = bid / per;  // 0..3; class 3 = (odd, odd) has the most taps and goes first
+    bid -= q * per;
+    ph = (3 - q) >> 1;
+    pw = (3 - q) & 1;
+  }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -98,18 +117,30 @@ igemm_kernel(ConvArgs a) {
   const int kc = t & (CPR - 1);
   const int trow = t / CPR;
 
+  // GEMM row -> output pixel.  PAR: rows enumerate the pixels of one parity class.
+  const int row_hw = PAR ? a.Ha * a.Wb : a.Ho * a.Wo;
+  const int row_w = PAR ? a.Wb : a.Wo;
+  auto decode = [&](int m, int& n, int& ho, int& wo) -> bool {
+    n = m / row_hw;
+    const int rem = m - n * row_hw;
+    ho = rem / row_w;
+    wo = rem - ho * row_w;
+    if (PAR) {
+      ho = 2 * ho + ph;
+      wo = 2 * wo + pw;
+      return m < a.M && ho < a.Ho && wo < a.Wo;
+    }
+    return m < a.M;
+  };
+
   // per-thread A rows: decompose m once, it does not change along K
   long long abase[A_IT];
   int ah0[A_IT], aw0[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + trow + i * RPT;
-    if (m < a.M) {
-      const int hw = a.Ho * a.Wo;
-      const int n = m / hw;
-      const int rem = m - n * hw;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
+    int n, ho, wo;
+    if (decode(m, n, ho, wo)) {
       abase[i] = (long long)n * a.sn + kc * EPC;
       if (DGRAD) {
         ah0[i] = ho + a.pad_h;
@@ -133,8 +164,14 @@ igemm_kernel(ConvArgs a) {
     bbase[i] = (long long)n * Ktot + kc * EPC;
   }
 
+  // taps visited: all of them, or (PAR) those with the parity of this class' pixels
+  const int r0 = PAR ? ((ph + a.pad_h) & 1) : 0, s0 = PAR ? ((pw + a.pad_w) & 1) : 0;
+  constexpr int TSTEP = PAR ? 2 : 1;
+  const int nr = PAR ? (a.R > r0 ? (a.R - r0 + 1) >> 1 : 0) : a.R;
+  const int ns = PAR ? (a.S > s0 ? (a.S - s0 + 1) >> 1 : 0) : a.S;
+
   u32x4 ra[A_IT], rb[B_IT];
-  int r = 0, s = 0, c0 = 0, kofs = 0;
+  int r = r0, s = s0, c0 = 0, kofs = (r0 * a.S + s0) * a.Ci;
 
   auto gload = [&]() {
 #pragma unroll
@@ -183,7 +220,9 @@ igemm_kernel(ConvArgs a) {
     c0 += BK;
     if (c0 >= a.Ci) {
       c0 = 0;
-      if (++s >= a.S) { s = 0; ++r; }
+      s += TSTEP;
+      if (s >= a.S) { s = s0; r += TSTEP; }
+      if (PAR) kofs = (r * a.S + s) * a.Ci;
     }
   };
 
@@ -195,9 +234,11 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  const int nk = a.R * a.S * (a.Ci / BK);
-  gload();
-  lstore(0);
+  const int nk = nr * ns * (a.Ci / BK);  // 0 for a parity class no tap reaches (e.g. 1x1 stride 2)
+  if (nk > 0) {
+    gload();
+    lstore(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -296,9 +337,16 @@ igemm_kernel(ConvArgs a) {
       const int v = t + 256 * k;
       const int row = v / VPR, cv = v % VPR;
       const int m = m0 + row, n = n0 + cv * EPC;
-      if (m < a.M && n < a.Co) {
+      bool rok = m < a.M;
+      long long orow = m;
+      if (PAR) {
+        int pn, pho, pwo;
+        rok = decode(m, pn, pho, pwo);
+        orow = ((long long)pn * a.Ho + pho) * a.Wo + pwo;
+      }
+      if (rok && n < a.Co) {
         Vec16<T> val = *reinterpret_cast<const Vec16<T>*>(lds + row * CP + cv * 16);
-        const long long o = (long long)m * a.Co + n;
+        const long long o = orow * a.Co + n;
         if (Rz != nullptr) {
           const Vec16<T> rv = load16(Rz + o);
 #pragma unroll
@@ -324,8 +372,15 @@ igemm_kernel(ConvArgs a) {
         for (int g = 0; g < 16; ++g) {
           const int m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
           float v = acc[i][j][g];
-          const bool ok = (m < a.M) && (n < a.Co);
-          const long long o = (long long)m * a.Co + n;
+          bool rok = m < a.M;
+          long long orow = m;
+          if (PAR) {
+            int pn, pho, pwo;
+            rok = decode(m, pn, pho, pwo);
+            orow = ((long long)pn * a.Ho + pho) * a.Wo + pwo;
+          }
+          const bool ok = rok && (n < a.Co);
+          const long long o = orow * a.Co + n;
           if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
           if (a.relu) v = fmaxf(v, 0.f);
           const T tv = ElemTraits<T>::from_f32(v);
@@ -599,6 +654,35 @@ __global__ void krsc_to_crsk_kernel(const TI* __restrict__ in, TO* __restrict__ 
   }
 }
 
+// The same layout change for a whole list of weights in one launch (every conv of a model, once per
+// optimizer step).  meta: int64 [ntensors][5] = {src, dst, K, RS, C}; blk: int32 [nblocks][4] =
+// {tensor, rs, k tile, c tile}; one block moves a 64(k) x 64(c) tile through LDS so both the reads
+// (along c) and the writes (along k) are contiguous.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256)
+krsc_to_crsk_batched_kernel(const long long* __restrict__ meta, const int* __restrict__ blk) {
+  __shared__ TO tile[64][65];
+  const int4 b = reinterpret_cast<const int4*>(blk)[blockIdx.x];
+  const long long* m = meta + (long long)b.x * 5;
+  const TI* __restrict__ in = reinterpret_cast<const TI*>(m[0]);
+  TO* __restrict__ out = reinterpret_cast<TO*>(m[1]);
+  const int K = (int)m[2], RS = (int)m[3], C = (int)m[4];
+  const int rs = b.y, k0 = b.z * 64, c0 = b.w * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int k = k0 + ty + 4 * i, c = c0 + tx;
+    if (k < K && c < C)
+      tile[ty + 4 * i][tx] = ElemTraits<TO>::from_f32(ElemTraits<TI>::to_f32(in[((long long)k * RS + rs) * C + c]));
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, k = k0 + tx;
+    if (k < K && c < C) out[((long long)c * RS + rs) * K + k] = tile[tx][ty + 4 * i];
+  }
+}
+
 // ------------------------------------------------------------- host side ----
 static int ilog2_exact(int v) {
   int l = 0;
@@ -609,10 +693,12 @@ static int ilog2_exact(int v) {
 template <typename T, int BM, int BN, int ROWB>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
-  if (dgrad)
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, true>), dim3(tiles), dim3(256), 0, st, a);
+  if (dgrad == MODE_DGRAD_S2)
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2>), dim3(4 * tiles), dim3(256), 0, st, a);
+  else if (dgrad == MODE_DGRAD)
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD>), dim3(tiles), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, false>), dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP>), dim3(tiles), dim3(256), 0, st, a);
   return pda_check_launch();
 }
 
@@ -659,9 +745,17 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
   a.R = R; a.S = S; a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
   a.sh_log2 = ilog2_exact(stride_h); a.sw_log2 = ilog2_exact(stride_w);
   a.M = N * Ho * Wo; a.relu = relu;
+  a.Ha = a.Wb = 0;
   if (a.M <= 0 || Co <= 0) return 0;
   if (dgrad && (a.sh_log2 < 0 || a.sw_log2 < 0)) return -3;
   if ((long long)N * Ho * Wo > 0x7fffffffLL) return -4;
+  if (dgrad) dgrad = MODE_DGRAD;
+  if (dgrad && stride_h == 2 && stride_w == 2 && (cfg & 16) == 0) {  // cfg bit 4 forces the generic path
+    dgrad = MODE_DGRAD_S2;
+    a.Ha = (Ho + 1) / 2;
+    a.Wb = (Wo + 1) / 2;
+    a.M = N * a.Ha * a.Wb;
+  }
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -5;
   switch (dtype) {
     case PDA_F16: return dispatch_igemm<f16>(a, dgrad, cfg, stream);
@@ -676,7 +770,10 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   const int tiles = ((a.Co + TM - 1) / TM) * ((a.Ktot + TN - 1) / TN);
   int nsplit = nsplit_hint;
   if (nsplit <= 0) {
-    nsplit = (1024 + tiles - 1) / tiles;  // aim for ~4 workgroups per CU
+    // ~2 workgroups per CU: enough to hide the staging latency, few enough that the float-atomic
+    // traffic of the split-K reduction (one tile of adds per workgroup) stays small
+    const int target = (TM >= 128 && TN >= 128) ? 512 : 640;
+    nsplit = (target + tiles / 2) / tiles;
     const int maxsplit = (a.M + 4 * BKP - 1) / (4 * BKP);
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
@@ -704,20 +801,49 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
   const int epc = 16 / es;
   if (Ci % epc != 0 || Co % epc != 0) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return -5;
+  // cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 64x64, 3 = 64(Co) x 128; bit 3 = 32 pixels per step
+  // instead of 64 (16-bit types).
   int tile = cfg & 7;
-  if (tile == 0) tile = (Co % 128 == 0 && a.Ktot % 128 == 0 && Co >= 128) ? 1 : 2;
+  if (tile == 0) {
+    if (Co % 128 == 0 && a.Ktot % 128 == 0) tile = 1;
+    else if (Co <= 64 && a.Ktot >= 256) tile = 3;
+    else tile = 2;
+  }
+  const bool bk32 = (cfg & 8) != 0;
+#define PDA_W16(T)                                                                        \
+  if (bk32) {                                                                             \
+    if (tile == 1) return launch_wgrad<T, 128, 128, 32>(a, nsplit, stream);               \
+    if (tile == 3) return launch_wgrad<T, 64, 128, 32>(a, nsplit, stream);                \
+    return launch_wgrad<T, 64, 64, 32>(a, nsplit, stream);                                \
+  }                                                                                       \
+  if (tile == 1) return launch_wgrad<T, 128, 128, 64>(a, nsplit, stream);                 \
+  if (tile == 3) return launch_wgrad<T, 64, 128, 64>(a, nsplit, stream);                  \
+  return launch_wgrad<T, 64, 64, 64>(a, nsplit, stream);
   switch (dtype) {
-    case PDA_F16:
-      return tile == 1 ? launch_wgrad<f16, 128, 128, 32>(a, nsplit, stream)
-                       : launch_wgrad<f16, 64, 64, 32>(a, nsplit, stream);
-    case PDA_BF16:
-      return tile == 1 ? launch_wgrad<bf16, 128, 128, 32>(a, nsplit, stream)
-                       : launch_wgrad<bf16, 64, 64, 32>(a, nsplit, stream);
+    case PDA_F16: { PDA_W16(f16) }
+    case PDA_BF16: { PDA_W16(bf16) }
     case PDA_F32:
       return tile == 1 ? launch_wgrad<float, 128, 128, 16>(a, nsplit, stream)
                        : launch_wgrad<float, 64, 64, 16>(a, nsplit, stream);
     default: return -6;
   }
+#undef PDA_W16
+}
+
+PDA_EXPORT int pda_krsc_to_crsk_batched(int dt_in, int dt_out, const long long* meta, const int* blk, int nblocks,
+                                        hipStream_t stream) {
+  if (nblocks <= 0) return 0;
+  if ((uintptr_t)blk & 15) return -5;
+#define PDA_T(TI, TO) \
+  hipLaunchKernelGGL((krsc_to_crsk_batched_kernel<TI, TO>), dim3(nblocks), dim3(256), 0, stream, meta, blk)
+  if (dt_in == PDA_F32 && dt_out == PDA_F32) PDA_T(float, float);
+  else if (dt_in == PDA_F32 && dt_out == PDA_F16) PDA_T(float, f16);
+  else if (dt_in == PDA_F32 && dt_out == PDA_BF16) PDA_T(float, bf16);
+  else if (dt_in == PDA_F16 && dt_out == PDA_F16) PDA_T(f16, f16);
+  else if (dt_in == PDA_BF16 && dt_out == PDA_BF16) PDA_T(bf16, bf16);
+  else return -6;
+#undef PDA_T
+  return pda_check_launch();
 }
 
 PDA_EXPORT int pda_krsc_to_crsk(int dt_in, int dt_out, const void* in, void* out, int K, int RS, int C,

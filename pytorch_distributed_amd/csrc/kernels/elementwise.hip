@@ -1,4 +1,4 @@
-// Memory-bound element-wise kernels (SURVEY K9, K15, K18, K19):
+// Memory-bound element-wise kernels:
 //  * input pipeline: NCHW (uint8 / fp32 / fp16) -> NHWC compute dtype with the
 //    per-channel (x - mean) / std of the loader fused in, optional channel
 //    padding (the ResNet stem wants 4 channels) and an optional zero border

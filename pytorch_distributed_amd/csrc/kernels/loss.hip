@@ -1,5 +1,5 @@
 // Softmax cross-entropy, log-softmax / NLL and accuracy counting, fused and
-// device-resident (SURVEY K13, K13b, K14; reference: nn.CrossEntropyLoss +
+// device-resident (reference: nn.CrossEntropyLoss +
 // accuracy() at /root/reference/2.distributed.py:118,214,344-364, the true top-k
 // variant at /root/reference/6.distributed_slurm_main.py:335-349 and
 // F.log_softmax/F.nll_loss at /root/reference/5.2.horovod_pytorch_mnist.py:52,64,90).

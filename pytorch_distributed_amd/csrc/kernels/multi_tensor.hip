@@ -1,5 +1,5 @@
 // Multi-tensor-apply kernels: one launch covers a whole list of tensors
-// (SURVEY N8, N9, N13, N14, K16, K17, K18, K20; the reference reaches apex's
+// (the reference reaches apex's
 // amp_C.multi_tensor_scale / multi_tensor_axpby / multi_tensor_l2norm through
 // `amp.scale_loss`, /root/reference/4.apex_distributed2.py:289-291, and
 // torch.optim.SGD.step through `optimizer.step()`, /root/reference/2.distributed.py:232).
@@ -189,7 +189,7 @@ mt_sgd_kernel(const long long* __restrict__ meta, const int* __restrict__ blk, c
   }
 }
 
-// Dynamic loss-scale state machine, on device (SURVEY N11): state = {scale,
+// Dynamic loss-scale state machine, on device: state = {scale,
 // growth_tracker, skipped_steps, last_overflow}.  Halve on overflow, double after
 // `interval` clean steps, clamp to [min_scale, max_scale]; clears the flag.
 __global__ void scaler_update_kernel(float* __restrict__ state, int* __restrict__ noop_flag, float growth,

@@ -1,6 +1,6 @@
 // Pooling for NHWC activations: max-pool (any window/stride/pad; ResNet stem
 // 3x3 s2 p1 and the 2x2 pools of the MNIST net) with a saved arg-max byte so the
-// backward is a gather, and global average pooling (SURVEY K10, K11; reference
+// backward is a gather, and global average pooling (reference
 // triggers: torchvision ResNet maxpool/avgpool under
 // /root/reference/2.distributed.py:213 and F.max_pool2d in
 // /root/reference/5.2.horovod_pytorch_mnist.py:46-47).

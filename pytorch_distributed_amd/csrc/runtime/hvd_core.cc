@@ -1,4 +1,4 @@
-// Horovod-style collective engine (SURVEY N16): what `hvd.init()` starts and what
+// Horovod-style collective engine: what `hvd.init()` starts and what
 // `hvd.allreduce_async_ / broadcast_async_ / synchronize / poll` talk to in the reference
 // (/root/reference/5.horovod_distributed.py:92,116-125, /root/reference/5.2.horovod_pytorch_mnist.py:77,174-185).
 //

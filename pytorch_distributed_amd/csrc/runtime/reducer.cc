@@ -1,4 +1,4 @@
-// Gradient-bucket reducer core (SURVEY N4): the bookkeeping half of
+// Gradient-bucket reducer core: the bookkeeping half of
 // DistributedDataParallel, i.e. what torch's C++ Reducer does behind
 // `DistributedDataParallel(model, device_ids=[rank])` and `loss.backward()`
 // (/root/reference/2.distributed.py:114,231), and apex DDP's arrival-order flat

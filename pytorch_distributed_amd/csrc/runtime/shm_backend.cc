@@ -1,4 +1,4 @@
-// Shared-memory CPU collective backend (SURVEY N3): all-reduce / broadcast /
+// Shared-memory CPU collective backend: all-reduce / broadcast /
 // all-gather / barrier between the processes of one host through a POSIX shm
 // segment.  It is the data plane of the Horovod-style API on CPU tensors
 // (`--no-cuda`, /root/reference/5.2.horovod_pytorch_mnist.py:22,75-78,112), the

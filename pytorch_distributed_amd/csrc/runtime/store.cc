@@ -1,4 +1,4 @@
-// Rendezvous key-value stores (SURVEY N1): the native piece behind
+// Rendezvous key-value stores: the native piece behind
 // init_process_group('tcp://...') / ('file://...') / env:// in the reference
 // (/root/reference/3.multiprocessing_distributed.py:102,
 //  /root/reference/6.distributed_slurm_main.py:93-101, /root/reference/2.distributed.py:98).

@@ -13,6 +13,7 @@ run under ``model(images)`` / ``loss.backward()`` in
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -163,7 +164,7 @@ class WeightCache:
     only when the parameter has changed (torch version counter or our optimizer's
     generation counter)."""
 
-    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp")
+    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "__weakref__")
 
     def __init__(self):
         self.pinned_lp = None  # (dtype, tensor, torch version) kept current by the optimizer kernel (amp O2)
@@ -171,6 +172,7 @@ class WeightCache:
         self.lp = None
         self.key_t = None
         self.t = None
+        self.t_weight = None   # weakref to the parameter the transpose in ``t`` belongs to
 
     @staticmethod
     def _key(weight: torch.Tensor, dtype) -> tuple:
@@ -194,9 +196,60 @@ class WeightCache:
     def transposed(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         key = self._key(weight, dtype)
         if self.key_t != key:
+            K, C, R, S = weight.shape
+            if (self.t is not None and self.t.dtype == dtype and self.t.shape == (C, R, S, K)
+                    and self.t.device == weight.device):
+                # a stale transpose of the same weight: the optimizer has stepped, so every conv of the
+                # model is stale too - refresh all of them with one launch
+                _refresh_transposes(dtype, weight.device)
+                if self.key_t == key:
+                    return self.t
             self.t = krsc_to_crsk(krsc(weight.detach()), dtype)
             self.key_t = key
+            self.t_weight = weakref.ref(weight)
+            _T_CACHES.add(self)
         return self.t
+
+
+_T_CACHES: "weakref.WeakSet[WeightCache]" = weakref.WeakSet()
+_T_TABLES: dict = {}
+
+
+def _refresh_transposes(dtype: torch.dtype, device) -> None:
+    """Recompute, in one launch, every registered CRSK transpose of ``dtype`` on ``device`` that is stale."""
+    todo = []
+    for c in _T_CACHES:
+        w = c.t_weight() if c.t_weight is not None else None
+        if w is None or c.t is None or c.t.dtype != dtype or c.t.device != device or w.device != device:
+            continue
+        key = WeightCache._key(w, dtype)
+        if c.key_t != key and c.t.shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]) \
+                and krsc(w.detach()).is_contiguous():
+            todo.append((c, w, key))
+    if not todo:
+        return
+    todo.sort(key=lambda e: e[1].data_ptr())
+    sig = (dtype, todo[0][1].dtype, tuple((w.data_ptr(), c.t.data_ptr()) for c, w, _ in todo))
+    tab = _T_TABLES.get(device)
+    if tab is None or tab[0] != sig:
+        if any(w.dtype != todo[0][1].dtype for _, w, _ in todo):
+            return  # mixed source dtypes: let the per-tensor path handle it
+        meta, blk = [], []
+        for i, (c, w, _) in enumerate(todo):
+            K, C, R, S = w.shape
+            meta.append([w.data_ptr(), c.t.data_ptr(), K, R * S, C])
+            for rs in range(R * S):
+                for kt in range((K + 63) // 64):
+                    for ct in range((C + 63) // 64):
+                        blk.append([i, rs, kt, ct])
+        tab = (sig, torch.tensor(meta, dtype=torch.int64).to(device), torch.tensor(blk, dtype=torch.int32).to(device),
+               len(blk))
+        _T_TABLES[device] = tab
+    l = _lib.lib()
+    _lib.check(l.pda_krsc_to_crsk_batched(_lib.dt(todo[0][1]), _lib.dt(dtype), tab[1].data_ptr(), tab[2].data_ptr(),
+                                          tab[3], _lib.stream()), "pda_krsc_to_crsk_batched")
+    for c, w, key in todo:
+        c.key_t = key
 
 
 # --------------------------------------------------------------------------- autograd op

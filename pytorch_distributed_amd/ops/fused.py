@@ -10,8 +10,7 @@
                    padded channels), followed by BN+ReLU and the 3x3/s2 max-pool.
 
 One autograd node per conv+BN+activation keeps the Python/autograd overhead of a
-ResNet-50 step at ~55 nodes instead of ~175 (SURVEY K1/K6/K8/K9 fusion plan;
-reference: the torchvision Bottleneck/BasicBlock forward under
+ResNet-50 step at ~55 nodes instead of ~175 (reference: the torchvision Bottleneck/BasicBlock forward under
 /root/reference/2.distributed.py:213).
 """
 from __future__ import annotations
@@ -50,6 +49,7 @@ class _ConvBnActFn(torch.autograd.Function):
             count = float(y.numel() // K)
         out = Nm.apply(y, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
+        ctx.beta = beta
         mask_src = out if (relu and (residual is not None or not train_stats)) else None
         ctx.save_for_backward(x, weight, y if train_stats else None, mask_src, mean, invstd, scale, shift, gamma)
         if passthrough:
@@ -66,7 +66,7 @@ class _ConvBnActFn(torch.autograd.Function):
         K, Cin, R, S = weight.shape
         if train_stats:
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
-                                           has_res, group)
+                                           has_res, group, ctx.beta)
         else:
             g = dout if not relu else dout * (mask_src > 0).to(dout.dtype)
             dy = (g.float() * scale).to(dout.dtype)
@@ -184,6 +184,7 @@ class _StemFn(torch.autograd.Function):
         else:
             out, idx = act, None
         ctx.cfg = (stride, pad, geom, count, st.group, pool, act.shape, train_stats, weight.shape)
+        ctx.beta = beta
         ctx.save_for_backward(xp, y if train_stats else None, idx, mean_, invstd, scale, shift, gamma,
                               act if not train_stats else None)
         return out
@@ -196,7 +197,8 @@ class _StemFn(torch.autograd.Function):
         K, Cin, R, S = wshape
         dact = P.maxpool_bwd_gpu(dout, idx, act_shape, *pool) if pool is not None else dout
         if train_stats:
-            dy, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group)
+            dy, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group,
+                                        ctx.beta)
         else:
             dy = ((dact * (act > 0).to(dact.dtype)).float() * scale).to(dact.dtype)
             dg = db = None

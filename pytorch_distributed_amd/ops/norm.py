@@ -6,7 +6,7 @@ GPU path = the kernels of ``csrc/kernels/bn.hip``; CPU path = ``F.batch_norm``.
 all-reduced between the statistics pass and the normalisation pass, and
 (sum dy, sum dy*xhat) in backward - two small all-reduces per layer per direction.
 Reference: torchvision BatchNorm2d under /root/reference/2.distributed.py:213;
-SyncBN itself is absent upstream and required by the port's north-star config.
+SyncBN itself is absent upstream; it is provided for small per-GPU batches.
 """
 from __future__ import annotations
 
@@ -72,14 +72,18 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState):
     rm = st.running_mean if (st.training and st.running_mean is not None) else None
     rv = st.running_var if (st.training and st.running_var is not None) else None
     mom = st.momentum
+    nbt = None
     if st.num_batches_tracked is not None and st.training:
-        st.num_batches_tracked += 1
-        if mom is None:  # cumulative moving average, as torch does for momentum=None
+        if mom is None:  # cumulative moving average, as torch does for momentum=None (needs the count on the host)
+            st.num_batches_tracked += 1
             mom = 1.0 / float(st.num_batches_tracked.item())
+        else:
+            nbt = st.num_batches_tracked  # incremented by the finalize kernel itself
     _lib.check(l.pda_bn_finalize(psum.data_ptr(), psq.data_ptr(), nparts, C, float(count), float(st.eps),
                                  float(mom if mom is not None else 0.1), _lib.ptr(gamma), _lib.ptr(beta),
                                  _lib.ptr(rm), _lib.ptr(rv), out[0].data_ptr(), out[1].data_ptr(),
-                                 out[2].data_ptr(), out[3].data_ptr(), _lib.stream()), "pda_bn_finalize")
+                                 out[2].data_ptr(), out[3].data_ptr(), _lib.ptr(nbt), _lib.stream()),
+               "pda_bn_finalize")
     return out[0], out[1], out[2], out[3], count
 
 
@@ -103,9 +107,22 @@ def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool
     return out
 
 
+def _vec_sink(param):
+    """``param.grad`` if this package may accumulate into it directly (see ``conv.grad_sink``)."""
+    if param is None or not getattr(param, "_pda_direct_grad", False):
+        return None
+    g = param.grad
+    if g is None or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
+
+
 def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu: bool, want_dres: bool,
-             group=None):
-    """-> dy, dres (or None), dgamma, dbeta."""
+             group=None, beta=None):
+    """-> dy, dres (or None), dgamma, dbeta.
+
+    When both affine parameters opted into direct gradient accumulation, their gradients are added
+    to ``.grad`` by the finalize kernel and ``None`` is returned for them."""
     l = _lib.lib()
     C = y.shape[-1]
     M = y.numel() // C
@@ -118,10 +135,13 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
     coef = torch.empty((5, C), device=dev, dtype=torch.float32)
     sync = _world(group) > 1
+    sink_g, sink_b = _vec_sink(gamma), _vec_sink(beta)
+    direct = sink_g is not None and sink_b is not None
     _lib.check(l.pda_bn_bwd_finalize(part[0].data_ptr(), part[1].data_ptr(), n, C, dgb[0].data_ptr(),
                                      dgb[1].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                      shift.data_ptr(), _lib.ptr(gamma), float(count),
-                                     0 if sync else coef.data_ptr(), _lib.stream()), "pda_bn_bwd_finalize")
+                                     0 if sync else coef.data_ptr(), sink_g.data_ptr() if direct else 0,
+                                     sink_b.data_ptr() if direct else 0, _lib.stream()), "pda_bn_bwd_finalize")
     if sync:
         import torch.distributed as dist
         tot = dgb.clone()
@@ -133,6 +153,12 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     dres = torch.empty_like(y) if want_dres else None
     _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), coef.data_ptr(),
                                   M, C, int(relu), dy.data_ptr(), _lib.ptr(dres), _lib.stream()), "pda_bn_bwd_apply")
+    if direct:
+        for p in (gamma, beta):
+            cb = getattr(p, "_pda_grad_ready", None)
+            if cb is not None:
+                cb()
+        return dy, dres, None, None
     return dy, dres, dgb[0], dgb[1]
 
 
@@ -156,6 +182,7 @@ class _BatchNormActFn(torch.autograd.Function):
         out = apply(y, scale, shift, residual, relu)
         ctx.relu, ctx.has_res, ctx.count, ctx.group = relu, residual is not None, count, st.group
         ctx.train = mean is not None
+        ctx.beta = beta
         if ctx.train:
             ctx.save_for_backward(y, out if (relu and residual is not None) else None, mean, invstd, scale, shift, gamma)
         else:
@@ -171,9 +198,12 @@ class _BatchNormActFn(torch.autograd.Function):
             return (g.float() * scale).to(dout.dtype), None, None, (g if ctx.has_res else None), None, None
         y, out, mean, invstd, scale, shift, gamma = ctx.saved_tensors
         dy, dres, dg, db = backward(dout, y, out, mean, invstd, scale, shift, gamma, ctx.count, ctx.relu,
-                                    ctx.has_res, ctx.group)
-        return (dy, dg.to(gamma.dtype) if gamma is not None else None,
-                db.to(gamma.dtype) if gamma is not None else None, dres, None, None)
+                                    ctx.has_res, ctx.group, ctx.beta)
+        if dg is not None and gamma is not None:
+            dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
+        else:
+            dg = db = None
+        return dy, dg, db, dres, None, None
 
 
 def batch_norm_act_ref(y, gamma, beta, residual, relu, st: BNState):

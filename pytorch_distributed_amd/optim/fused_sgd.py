@@ -27,6 +27,10 @@ from ..ops import multi_tensor as mt
 from ..ops.conv import bump_param_generation
 
 
+def _dense_like(p: torch.Tensor) -> bool:
+    return p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+
+
 class FusedSGD(Optimizer):
     def __init__(self, params, lr: float = 0.1, momentum: float = 0.0, dampening: float = 0.0,
                  weight_decay: float = 0.0, nesterov: bool = False):
@@ -53,6 +57,62 @@ class FusedSGD(Optimizer):
         assert copy.numel() == param.numel()
         self._model_copies[id(param)] = copy
         self._lists.clear()
+
+    # -- gradient arena ---------------------------------------------------------------------
+    def _build_arena(self) -> None:
+        """Re-home every existing fp32 device gradient into one flat buffer per device, so that
+        clearing the gradients is one memset instead of one fill kernel per parameter."""
+        self._arena = {}
+        self._arena_ptrs = []
+        per_dev: Dict[torch.device, List[torch.Tensor]] = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                gr = p.grad
+                if gr is not None and gr.is_cuda and gr.dtype == torch.float32 and gr.shape == p.shape:
+                    per_dev.setdefault(gr.device, []).append(p)
+        for dev, ps in per_dev.items():
+            offs, total = [], 0
+            for p in ps:
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64  # 256-byte aligned slots keep 16-byte vector access legal
+            flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            for p, o in zip(ps, offs):
+                # same logical shape AND memory format as the parameter (conv weights are channels-last)
+                view = torch.as_strided(flat, p.shape, p.stride(), o) if _dense_like(p) else None
+                if view is None:
+                    continue
+                p.grad = view
+                self._arena_ptrs.append((p, view.data_ptr()))
+            self._arena[dev] = flat
+        self._lists.clear()
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """``set_to_none=False`` (the default here, unlike torch): gradients persist, which is what lets
+        the conv / BatchNorm backward kernels accumulate into them directly."""
+        if set_to_none:
+            self._arena = None
+            return super().zero_grad(set_to_none=True)
+        arena = getattr(self, "_arena", None)
+        if arena is not None and all(p.grad is not None and p.grad.data_ptr() == ptr for p, ptr in self._arena_ptrs):
+            covered = {id(p) for p, _ in self._arena_ptrs}
+            for flat in arena.values():
+                flat.zero_()
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is not None and id(p) not in covered:
+                        p.grad.zero_()
+            return
+        params = [p for g in self.param_groups for p in g["params"]]
+        managed = any(hasattr(p, "_pda_grad_ready") for p in params)  # a DDP wrapper owns the gradient storage
+        if not managed and any(p.grad is not None and p.grad.is_cuda for p in params):
+            self._build_arena()  # fresh zeros
+            covered = {id(p) for p, _ in self._arena_ptrs}
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is not None and id(p) not in covered:
+                        p.grad.zero_()
+            return
+        super().zero_grad(set_to_none=False)
 
     # -- helpers ----------------------------------------------------------------------------
     def _group_hp(self, gi: int, group, device) -> torch.Tensor:

@@ -80,6 +80,29 @@ def test_conv_tile_configs(cfg):
     assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, R, pad  (stride 2 everywhere)
+    (2, 14, 14, 64, 128, 3, 1), (3, 7, 9, 128, 64, 3, 1), (2, 16, 16, 256, 128, 1, 0), (1, 15, 13, 64, 64, 1, 0),
+    (2, 12, 12, 64, 64, 5, 2), (70, 4, 4, 64, 64, 3, 1)])
+def test_dgrad_stride2_parity_split(case, dtype):
+    """Stride-2 dgrad by parity class == the every-tap kernel == autograd, with and without a residual."""
+    N, H, W, Cin, K, R, p = case
+    torch.manual_seed(11)
+    w = (torch.randn(K, R, R, Cin, device=DEV) / (R * R * Cin) ** 0.5).to(dtype).permute(0, 3, 1, 2)
+    xr = torch.zeros(N, H, W, Cin, device=DEV, requires_grad=True)
+    yr = _ref_conv(xr, w.float(), 2, p)
+    dy = torch.randn_like(yr).to(dtype)
+    yr.backward(dy.float())
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    res = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    for cfg in (0, 3, 16):
+        dx = C.dgrad_gpu(dy, wt, (H, W), (2, 2), (p, p), cfg=cfg)
+        assert rel_err(dx, xr.grad) < TOL[dtype], cfg
+        dx = C.dgrad_gpu(dy, wt, (H, W), (2, 2), (p, p), res=res, cfg=cfg)
+        assert rel_err(dx, xr.grad + res.float()) < TOL[dtype], ("res", cfg)
+
+
 def test_conv_epilogue_residual_relu():
     torch.manual_seed(3)
     x = torch.randn(2, 8, 8, 64, device=DEV).half()
@@ -97,10 +120,60 @@ def test_wgrad_tiles_and_splits():
     dy = torch.randn(N, H, W, K, device=DEV).half()
     wr = torch.zeros(K, Cin, 3, 3, device=DEV, requires_grad=True)
     _ref_conv(x, wr, 1, 1).backward(dy.float())
-    for cfg in (1, 2):
+    for cfg in (1, 2, 3, 9, 10, 11):
         for nsplit in (0, 1, 3):
             dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), cfg=cfg, nsplit=nsplit)
             assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-2, (cfg, nsplit)
+
+
+def test_batched_weight_transpose_refresh():
+    """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
+    torch.manual_seed(41)
+    shapes = [(64, 64, 1, 1), (128, 64, 3, 3), (256, 128, 1, 1), (72, 40, 3, 3)]
+    ws = [C.make_weight(*s, device=DEV).normal_() for s in shapes]
+    caches = [C.WeightCache() for _ in ws]
+    for w, c in zip(ws, caches):
+        t = c.transposed(w, torch.float16)
+        assert torch.equal(t, C.krsc(w).permute(3, 1, 2, 0).contiguous().half())
+    ptrs = [c.t.data_ptr() for c in caches]
+    for w in ws:
+        w.data.mul_(-0.5)          # no version bump on .data: emulate the fused optimizer ...
+    C.bump_param_generation()      # ... which signals the change through the generation counter
+    t0 = caches[0].transposed(ws[0], torch.float16)
+    assert t0.data_ptr() == ptrs[0]
+    for w, c, p in zip(ws, caches, ptrs):
+        assert c.key_t == C.WeightCache._key(w, torch.float16)       # all refreshed by the first request
+        assert c.t.data_ptr() == p
+        assert torch.equal(c.t, C.krsc(w).permute(3, 1, 2, 0).contiguous().half())
+
+
+def test_direct_param_grads_and_arena():
+    """conv weight and BN affine gradients accumulate straight into the optimizer's flat gradient arena."""
+    from pytorch_distributed_amd.optim import FusedSGD
+    torch.manual_seed(42)
+    conv = pnn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    bn = pnn.BatchNorm2d(64).to(DEV)
+    opt = FusedSGD(list(conv.parameters()) + list(bn.parameters()), lr=0.0)
+    x = torch.randn(4, 10, 10, 64, device=DEV).half()
+    g = torch.randn(4, 10, 10, 64, device=DEV).half()
+
+    def run():
+        out = pnn.ConvBnAct.run(conv, bn, x, relu=True)
+        out.backward(g)
+
+    run()                                   # autograd allocates the gradients
+    ref = [p.grad.clone() for p in (conv.weight, bn.weight, bn.bias)]
+    opt.zero_grad()                         # builds the arena
+    assert opt._arena is not None and len(opt._arena_ptrs) == 3
+    run()                                   # direct accumulation into arena views
+    for p, r in zip((conv.weight, bn.weight, bn.bias), ref):
+        assert rel_err(p.grad, r) < 1e-3
+    run()                                   # accumulates on top
+    for p, r in zip((conv.weight, bn.weight, bn.bias), ref):
+        assert rel_err(p.grad, 2 * r) < 1e-3
+    opt.zero_grad()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in (conv.weight, bn.weight, bn.bias))
+    assert int(bn.num_batches_tracked) == 3
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
