@@ -87,7 +87,7 @@ def main():
             ktot = k * k * ci
             tile = wc & 7
             if tile == 0:
-                tile = 1 if (co % 128 == 0 and ktot % 128 == 0) else (3 if (co <= 64 and ktot >= 256) else 2)
+                tile = 1 if (co % 128 == 0 and ktot % 128 == 0) else 2
             tlm, tln = {1: (128, 128), 2: (64, 64), 3: (64, 128)}[tile]
             tiles = -(-co // tlm) * -(-ktot // tln)
             splits = [int(c) for c in a.nsplits.split(",")]

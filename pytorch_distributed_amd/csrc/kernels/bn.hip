@@ -80,60 +80,77 @@ bn_stats_partial_kernel(const T* __restrict__ y, long long M, int C, float* __re
   }
 }
 
-// Reduce [nparts][C] partial sums to per-channel totals inside one block:
-// 1024 threads = 16 channels x 64 partial lanes (coalesced 64-byte row segments,
-// fp64 accumulation), then a 64-way LDS tree.  Returns the totals to the 16
-// threads with pl == 0.
-__device__ __forceinline__ void reduce_partials_16x64(const float* __restrict__ pa, const float* __restrict__ pb,
-                                                      int nparts, int C, int c, int pl, double& ra, double& rb,
-                                                      double (*red)[64][17]) {
-  double a = 0.0, b = 0.0;
-  if (c < C) {
-    int p = pl;
-    for (; p + 192 < nparts; p += 256) {  // 4 independent loads in flight per array
-      const float a0 = pa[(long long)p * C + c], a1 = pa[(long long)(p + 64) * C + c];
-      const float a2 = pa[(long long)(p + 128) * C + c], a3 = pa[(long long)(p + 192) * C + c];
-      const float b0 = pb[(long long)p * C + c], b1 = pb[(long long)(p + 64) * C + c];
-      const float b2 = pb[(long long)(p + 128) * C + c], b3 = pb[(long long)(p + 192) * C + c];
-      a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+// Reduce [nparts][C] partial sums to per-channel totals inside one block of 1024 threads =
+// CH channels x NL = 1024/CH partial lanes (fp64 accumulation, 4 independent loads in flight per
+// array), then an NL-way LDS tree.  Returns the totals to the CH threads with pl == 0.
+// CH = 16 reads coalesced 64-byte row segments; CH = 4 trades that for 4x more workgroups and 4x
+// shorter per-lane loops, which is what matters when C is small and nparts is in the thousands
+// (one partial row per conv tile: the early ResNet stages at large batch).
+// With clear != 0 every partial is zeroed after it has been read (self-cleaning accumulation rows).
+template <int CH>
+struct PartialReduce {
+  static constexpr int NL = 1024 / CH;
+  typedef double Scratch[2][NL][CH + 1];
+  static __device__ __forceinline__ void run(float* __restrict__ pa, float* __restrict__ pb, int nparts, int C,
+                                             int& c, int& pl, double& ra, double& rb, Scratch& red, int clear = 0) {
+    const int cl = threadIdx.x % CH;
+    c = blockIdx.x * CH + cl;
+    pl = threadIdx.x / CH;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+      int p = pl;
+      for (; p + 3 * NL < nparts; p += 4 * NL) {
+        const float a0 = pa[(long long)p * C + c], a1 = pa[(long long)(p + NL) * C + c];
+        const float a2 = pa[(long long)(p + 2 * NL) * C + c], a3 = pa[(long long)(p + 3 * NL) * C + c];
+        const float b0 = pb[(long long)p * C + c], b1 = pb[(long long)(p + NL) * C + c];
+        const float b2 = pb[(long long)(p + 2 * NL) * C + c], b3 = pb[(long long)(p + 3 * NL) * C + c];
+        a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+      }
+      for (; p < nparts; p += NL) {
+        a += (double)pa[(long long)p * C + c];
+        b += (double)pb[(long long)p * C + c];
+      }
+      if (clear)
+        for (p = pl; p < nparts; p += NL) {
+          pa[(long long)p * C + c] = 0.f;
+          pb[(long long)p * C + c] = 0.f;
+        }
     }
-    for (; p < nparts; p += 64) {
-      a += (double)pa[(long long)p * C + c];
-      b += (double)pb[(long long)p * C + c];
-    }
-  }
-  const int cl = threadIdx.x & 15;
-  red[0][pl][cl] = a;
-  red[1][pl][cl] = b;
-  __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (pl < s) {
-      red[0][pl][cl] += red[0][pl + s][cl];
-      red[1][pl][cl] += red[1][pl + s][cl];
-    }
+    red[0][pl][cl] = a;
+    red[1][pl][cl] = b;
     __syncthreads();
+    for (int s = NL / 2; s > 0; s >>= 1) {
+      if (pl < s) {
+        red[0][pl][cl] += red[0][pl + s][cl];
+        red[1][pl][cl] += red[1][pl + s][cl];
+      }
+      __syncthreads();
+    }
+    ra = red[0][0][cl];
+    rb = red[1][0][cl];
   }
-  ra = red[0][0][cl];
-  rb = red[1][0][cl];
-}
+};
+
+// channels per block for the finalize-type kernels
+static inline int partial_ch(int nparts, int C) { return (nparts > 512 && C < 16 * 96) ? 4 : 16; }
 
 // count = number of reduced elements per channel (over all ranks for SyncBN).
 // Updates running stats in place (momentum, unbiased variance) and emits
-// mean / invstd / scale / shift.  Grid = ceil(C/16) blocks of 1024 threads.
+// mean / invstd / scale / shift.  Grid = ceil(C/CH) blocks of 1024 threads.
+template <int CH>
 __global__ void __launch_bounds__(1024)
-bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
+bn_finalize_kernel(float* __restrict__ psum, float* __restrict__ psq, int nparts,
                                    int C, double count, float eps, float momentum,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   long long* __restrict__ num_batches_tracked) {
-  __shared__ double red[2][64][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int pl = threadIdx.x >> 4;
+                                   long long* __restrict__ num_batches_tracked, int clear) {
+  __shared__ typename PartialReduce<CH>::Scratch red;
+  int c, pl;
   double s, q;
-  reduce_partials_16x64(psum, psq, nparts, C, c, pl, s, q, red);
+  PartialReduce<CH>::run(psum, psq, nparts, C, c, pl, s, q, red, clear);
   if (pl != 0 || c >= C) return;
   if (num_batches_tracked && c == 0) num_batches_tracked[0] += 1;
   const double mean = s / count;
@@ -154,14 +171,14 @@ bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq
 }
 
 // sums[0][c] = sum over partials, sums[1][c] = sum of squares (fp32 out, fp64 math)
+template <int CH>
 __global__ void __launch_bounds__(1024)
-bn_reduce_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts, int C,
-                          float* __restrict__ sums) {
-  __shared__ double red[2][64][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int pl = threadIdx.x >> 4;
+bn_reduce_partials_kernel(float* __restrict__ psum, float* __restrict__ psq, int nparts, int C,
+                          float* __restrict__ sums, int clear) {
+  __shared__ typename PartialReduce<CH>::Scratch red;
+  int c, pl;
   double s, q;
-  reduce_partials_16x64(psum, psq, nparts, C, c, pl, s, q, red);
+  PartialReduce<CH>::run(psum, psq, nparts, C, c, pl, s, q, red, clear);
   if (pl != 0 || c >= C) return;
   sums[c] = (float)s;
   sums[C + c] = (float)q;
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                      const float* __restrict__ mean, const float* __restrict__ invstd,
                      const float* __restrict__ scale, const float* __restrict__ shift, long long M, int C,
-                     int relu, float* __restrict__ pdg, float* __restrict__ pdb) {
+                     int relu, float* __restrict__ pdg, float* __restrict__ pdb, int slots) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ float red[2][256 * EPC];
   ColGeom<T> g(C, blockIdx.y);
@@ -307,8 +324,13 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
         a += red[0][(w * 64 + l) * EPC + e];
         b += red[1][(w * 64 + l) * EPC + e];
       }
-      pdg[(long long)blockIdx.x * C + g.vec * EPC + e] = a;
-      pdb[(long long)blockIdx.x * C + g.vec * EPC + e] = b;
+      if (slots > 0) {  // pre-zeroed accumulation rows shared by many workgroups
+        atomicAdd(pdg + (long long)(blockIdx.x % slots) * C + g.vec * EPC + e, a);
+        atomicAdd(pdb + (long long)(blockIdx.x % slots) * C + g.vec * EPC + e, b);
+      } else {
+        pdg[(long long)blockIdx.x * C + g.vec * EPC + e] = a;
+        pdb[(long long)blockIdx.x * C + g.vec * EPC + e] = b;
+      }
     }
   }
 }
@@ -374,17 +396,18 @@ __device__ __forceinline__ void bwd_coefs(int c, int C, float dg, float db, cons
   coef[4 * C + c] = shift[c];
 }
 
+template <int CH>
 __global__ void __launch_bounds__(1024)
-bn_bwd_finalize_kernel(const float* __restrict__ pdg, const float* __restrict__ pdb, int nparts, int C,
+bn_bwd_finalize_kernel(float* __restrict__ pdg, float* __restrict__ pdb, int nparts, int C,
                        float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ mean,
                        const float* __restrict__ invstd, const float* __restrict__ scale,
                        const float* __restrict__ shift, const float* __restrict__ gamma, float inv_count,
-                       float* __restrict__ coef, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
-  __shared__ double red[2][64][17];
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int pl = threadIdx.x >> 4;
+                       float* __restrict__ coef, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta,
+                       int clear) {
+  __shared__ typename PartialReduce<CH>::Scratch red;
+  int c, pl;
   double a, b;
-  reduce_partials_16x64(pdg, pdb, nparts, C, c, pl, a, b, red);
+  PartialReduce<CH>::run(pdg, pdb, nparts, C, c, pl, a, b, red, clear);
   if (pl != 0 || c >= C) return;
   dgamma[c] = (float)a;
   dbeta[c] = (float)b;
@@ -446,20 +469,29 @@ PDA_EXPORT int pda_bn_stats_partial(int dtype, const void* y, long long M, int C
   return pda_check_launch();
 }
 
-PDA_EXPORT int pda_bn_reduce_partials(const float* psum, const float* psq, int nparts, int C, float* sums,
+PDA_EXPORT int pda_bn_reduce_partials(float* psum, float* psq, int nparts, int C, float* sums, int clear,
                                       hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C,
-                     sums);
+  if (partial_ch(nparts, C) == 4)
+    hipLaunchKernelGGL(bn_reduce_partials_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, psum, psq, nparts, C,
+                       sums, clear);
+  else
+    hipLaunchKernelGGL(bn_reduce_partials_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C,
+                       sums, clear);
   return pda_check_launch();
 }
 
-PDA_EXPORT int pda_bn_finalize(const float* psum, const float* psq, int nparts, int C, double count, float eps,
+PDA_EXPORT int pda_bn_finalize(float* psum, float* psq, int nparts, int C, double count, float eps,
                                float momentum, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                               float* shift_out, long long* num_batches_tracked, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
-                     eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
-                     shift_out, num_batches_tracked);
+                               float* shift_out, long long* num_batches_tracked, int clear, hipStream_t st) {
+  if (partial_ch(nparts, C) == 4)
+    hipLaunchKernelGGL(bn_finalize_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, psum, psq, nparts, C, count,
+                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked, clear);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
+                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked, clear);
   return pda_check_launch();
 }
 
@@ -498,24 +530,30 @@ PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out
 
 PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* mean,
                                  const float* invstd, const float* scale, const float* shift, long long M, int C,
-                                 int relu, float* pdg, float* pdb, hipStream_t st) {
+                                 int relu, float* pdg, float* pdb, int slots, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0) return -1;
   const int nb = pda_bn_num_partials(M, C, dtype);
   PDA_DISPATCH_T(dtype,
                  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256), 0, st,
                                     (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift, M, C,
-                                    relu, pdg, pdb));
+                                    relu, pdg, pdb, slots));
   return pda_check_launch();
 }
 
 // Reduce dgamma/dbeta partials; with coef != null also emits the bwd-apply coefficients ([5][C]).
-PDA_EXPORT int pda_bn_bwd_finalize(const float* pdg, const float* pdb, int nparts, int C, float* dgamma,
+PDA_EXPORT int pda_bn_bwd_finalize(float* pdg, float* pdb, int nparts, int C, float* dgamma,
                                    float* dbeta, const float* mean, const float* invstd, const float* scale,
                                    const float* shift, const float* gamma, double count, float* coef,
-                                   float* acc_dgamma, float* acc_dbeta, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, st, pdg, pdb, nparts, C, dgamma,
-                     dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma, acc_dbeta);
+                                   float* acc_dgamma, float* acc_dbeta, int clear, hipStream_t st) {
+  if (partial_ch(nparts, C) == 4)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, pdg, pdb, nparts, C, dgamma,
+                       dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma, acc_dbeta,
+                       clear);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, pdg, pdb, nparts, C,
+                       dgamma, dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma,
+                       acc_dbeta, clear);
   return pda_check_launch();
 }
 

@@ -37,14 +37,15 @@ struct ConvArgs {
   int M;                 // GEMM rows (per parity class in the stride-2 dgrad mode)
   int relu;
   int Ha, Wb;            // stride-2 dgrad: pixels per parity class along h / w
+  int stat_slots;        // 0: psum/psq hold one row per M tile; n > 0: n rows, float-atomic accumulated
 };
 
 // MODE 0: fprop.  MODE 1: dgrad, any power-of-two stride: every tap is visited and rows whose tap
 // does not land on an output pixel of the forward conv load zeros.  MODE 2: dgrad for stride 2,
 // split by the parity (h&1, w&1) of the input-gradient pixel: a pixel of one parity class only ever
 // receives the taps r = (h+pad) mod 2, +2, ... (likewise s), so each class is its own small
-// stride-1 GEMM over dY with 1/4 of the taps on average and no zero rows; one launch runs the
-// four classes back to back, heaviest first.
+// stride-1 GEMM over dY with 1/4 of the taps on average and no zero rows; one launch runs all
+// four classes, the classes of one tile position as neighbouring workgroups.
 enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_DGRAD_S2 = 2 };
 
 template <typename T> struct Mfma32;
@@ -70,7 +71,7 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 }
 
 template <typename T, int BM, int BN, int ROWB, int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 igemm_kernel(ConvArgs a) {
   constexpr bool DGRAD = MODE != MODE_FPROP;
   constexpr bool PAR = MODE == MODE_DGRAD_S2;
@@ -101,11 +102,16 @@ igemm_kernel(ConvArgs a) {
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   int ph = 0, pw = 0;
   if (PAR) {
-    const int per = tiles_m * tiles_n;
-    const int q = bid / per;  // 0..3; class 3 = (odd, odd) has the most taps and goes first
-    bid -= q * per;
-    ph = (3 - q) >> 1;
-    pw = (3 - q) & 1;
+    // the four classes of one tile position run as neighbouring workgroups (same XCD after the
+    // remap): they gather the same dY region and together write whole runs of output pixels
+    // The class rotates with the tile index: workgroups go to the shader engines of an XCD
+    // round-robin, so a fixed "class = id mod 4" would hand every workgroup of the heaviest class
+    // (4 taps of a 3x3, or the only live class of a 1x1) to the same engine.
+    const int grp = bid >> 2;
+    const int cls = (bid + grp) & 3;
+    ph = cls >> 1;
+    pw = cls & 1;
+    bid = grp;
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -309,6 +315,10 @@ igemm_kernel(ConvArgs a) {
   // 16-bit types with a vector-friendly Co: stage the tile through LDS so the global
   // stores (and the residual loads) are whole 16-byte vectors, 16 lanes per 256-byte row
   // segment, instead of 2-byte accesses scattered over 64-byte pieces.
+  // Row -> pixel arithmetic of the epilogue must not be scheduled ahead of the main loop (it would
+  // sit in registers for the whole loop and cost a wave of occupancy): hide m0 behind an opaque copy.
+  int m0e = m0;
+  if (PAR) asm volatile("" : "+v"(m0e));
   const bool vec_epi = (sizeof(T) == 2) && (a.Co % EPC == 0);
   if (vec_epi) {
     constexpr int CP = BN * (int)sizeof(T) + 16;  // padded row pitch, keeps 16-byte alignment
@@ -336,7 +346,7 @@ igemm_kernel(ConvArgs a) {
     for (int k = 0; k < BM * VPR / 256; ++k) {
       const int v = t + 256 * k;
       const int row = v / VPR, cv = v % VPR;
-      const int m = m0 + row, n = n0 + cv * EPC;
+      const int m = m0e + row, n = n0 + cv * EPC;
       bool rok = m < a.M;
       long long orow = m;
       if (PAR) {
@@ -370,7 +380,7 @@ igemm_kernel(ConvArgs a) {
         const int n = n0 + wn * WTN + j * 32 + l31;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-          const int m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          const int m = m0e + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
           float v = acc[i][j][g];
           bool rok = m < a.M;
           long long orow = m;
@@ -410,8 +420,18 @@ igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
     if (t < BN && n0 + t < a.Co) {
-      a.psum[(long long)tm * a.Co + n0 + t] = sred[t * 2] + sred[(BN + t) * 2];
-      a.psq[(long long)tm * a.Co + n0 + t] = sred[t * 2 + 1] + sred[(BN + t) * 2 + 1];
+      const float v1 = sred[t * 2] + sred[(BN + t) * 2];
+      const float v2 = sred[t * 2 + 1] + sred[(BN + t) * 2 + 1];
+      if (a.stat_slots > 0) {
+        // few, pre-zeroed rows shared by many tiles: the finalize kernel that follows reads
+        // stat_slots rows instead of one per tile (thousands for the early ResNet stages)
+        const long long o = (long long)(tm % a.stat_slots) * a.Co + n0 + t;
+        atomicAdd(a.psum + o, v1);
+        atomicAdd(a.psq + o, v2);
+      } else {
+        a.psum[(long long)tm * a.Co + n0 + t] = v1;
+        a.psq[(long long)tm * a.Co + n0 + t] = v2;
+      }
     }
   }
 }
@@ -737,8 +757,10 @@ PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) { return pick_tile(M, C
 PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
                               float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
                               long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
-                              int stride_w, int pad_h, int pad_w, int relu, int cfg, hipStream_t stream) {
+                              int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
+                              hipStream_t stream) {
   ConvArgs a;
+  a.stat_slots = stat_slots;
   a.x = x; a.w = w; a.y = y; a.res = res; a.psum = psum; a.psq = psq;
   a.sn = sn; a.sh = sh; a.sw = sw;
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co;
@@ -772,8 +794,9 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   if (nsplit <= 0) {
     // ~2 workgroups per CU: enough to hide the staging latency, few enough that the float-atomic
     // traffic of the split-K reduction (one tile of adds per workgroup) stays small
-    const int target = (TM >= 128 && TN >= 128) ? 512 : 640;
-    nsplit = (target + tiles / 2) / tiles;
+    // (the 128x128 / 64-pixel configuration holds 2 workgroups per CU: stay within one round of 512)
+    if (TM >= 128 && TN >= 128) nsplit = 512 / tiles;
+    else nsplit = (704 + tiles / 2) / tiles;
     const int maxsplit = (a.M + 4 * BKP - 1) / (4 * BKP);
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
@@ -805,9 +828,7 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
   // instead of 64 (16-bit types).
   int tile = cfg & 7;
   if (tile == 0) {
-    if (Co % 128 == 0 && a.Ktot % 128 == 0) tile = 1;
-    else if (Co <= 64 && a.Ktot >= 256) tile = 3;
-    else tile = 2;
+    tile = (Co % 128 == 0 && a.Ktot % 128 == 0) ? 1 : 2;
   }
   const bool bk32 = (cfg & 8) != 0;
 #define PDA_W16(T)                                                                        \

@@ -278,8 +278,10 @@ class Engine {
     for (;;) {
       {
         std::unique_lock<std::mutex> g(mu_);
-        cv_.wait_for(g, std::chrono::microseconds((long long)(cycle_ms_ * 1000)),
-                     [&] { return stop_requested_ || !queue_.empty(); });
+        // system_clock deadline -> pthread_cond_timedwait, which ThreadSanitizer models (the
+        // steady-clock wait_for maps to pthread_cond_clockwait, which older TSan runtimes do not)
+        cv_.wait_until(g, std::chrono::system_clock::now() + std::chrono::microseconds((long long)(cycle_ms_ * 1000)),
+                       [&] { return stop_requested_ || !queue_.empty(); });
       }
       cycles_.fetch_add(1);
       std::string mine;

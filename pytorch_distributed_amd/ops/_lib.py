@@ -29,7 +29,7 @@ c_ull = ctypes.c_ulonglong
 _SIGS = {
     "pda_conv_igemm_bm": [c_i, c_i, c_i],
     "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
-                       c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+                       c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_krsc_to_crsk": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
@@ -38,12 +38,12 @@ _SIGS = {
                         c_i, c_i, c_p],
     "pda_bn_num_partials": [c_ll, c_i, c_i],
     "pda_bn_stats_partial": [c_i, c_p, c_ll, c_i, c_p, c_p, c_p],
-    "pda_bn_reduce_partials": [c_p, c_p, c_i, c_i, c_p, c_p],
-    "pda_bn_finalize": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "pda_bn_reduce_partials": [c_p, c_p, c_i, c_i, c_p, c_i, c_p],
+    "pda_bn_finalize": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "pda_bn_eval_coeffs": [c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "pda_bn_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
-    "pda_bn_bwd_reduce": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
-    "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p],
+    "pda_bn_bwd_reduce": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_i, c_p],
+    "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_i, c_p],
     "pda_bn_bwd_coefs": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p],
     "pda_bn_bwd_apply": [c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
     "pda_maxpool_fwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

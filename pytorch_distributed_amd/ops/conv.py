@@ -13,6 +13,7 @@ run under ``model(images)`` / ``loss.backward()`` in
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -22,6 +23,10 @@ import torch.nn.functional as F
 from . import _lib
 
 _PARAM_GENERATION = 0  # bumped by our optimizers, which update weights behind autograd's back
+# BatchNorm statistic partials: one row per tile (default), or PDA_STAT_SLOTS=1 = a few float-atomic
+# accumulation rows (shorter finalize, but measured slower end to end on MI355X: the atomics cost more
+# in the conv / reduce epilogues than the finalize kernels save)
+_STAT_SLOTS_OFF = os.environ.get("PDA_STAT_SLOTS", "0") != "1"
 
 
 def bump_param_generation() -> None:
@@ -51,11 +56,14 @@ def make_weight(k: int, c: int, r: int, s: int, device=None, dtype=torch.float32
 # --------------------------------------------------------------------------- raw GPU launches
 def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pad: Tuple[int, int],
               res: Optional[torch.Tensor] = None, relu: bool = False, stats: bool = False, cfg: int = 0,
-              geom: Optional[tuple] = None):
+              geom: Optional[tuple] = None, stats_buf: Optional[torch.Tensor] = None):
     """y = conv(x, w) [+ res] [relu]; optionally also per-tile column sums for BatchNorm.
 
     ``geom`` overrides the gather geometry ``(N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S)`` for inputs
-    that are not plain NHWC (the padded 4-channel stem image).
+    that are not plain NHWC (the padded 4-channel stem image).  ``stats_buf`` (fp32 ``[2, slots, K]``,
+    all zeros on entry) makes the kernel accumulate the statistics into ``slots`` rows with float
+    atomics instead of writing one row per tile; whoever consumes them must zero them again
+    (``norm.finalize(..., clear=True)``).
     """
     l = _lib.lib()
     K = w_krsc.shape[0]
@@ -69,14 +77,19 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     M = N * Ho * Wo
     y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
     psum = psq = None
+    slots = 0
     if stats:
         bm = l.pda_conv_igemm_bm(M, K, cfg)
         tiles_m = (M + bm - 1) // bm
-        part = torch.empty((2, tiles_m, K), device=x.device, dtype=torch.float32)
-        psum, psq = part[0], part[1]
+        if stats_buf is not None and tiles_m > stats_buf.shape[1]:
+            slots = stats_buf.shape[1]
+            psum, psq = stats_buf[0], stats_buf[1]
+        else:
+            part = torch.empty((2, tiles_m, K), device=x.device, dtype=torch.float32)
+            psum, psq = part[0], part[1]
     rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res),
                           _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
-                          stride[0], stride[1], pad[0], pad[1], int(relu), cfg, _lib.stream())
+                          stride[0], stride[1], pad[0], pad[1], int(relu), cfg, slots, _lib.stream())
     if rc < 0:
         return None  # shape not covered by the MFMA kernels
     _lib.check(rc, "pda_conv_igemm(fprop)")
@@ -93,7 +106,7 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
     rc = l.pda_conv_igemm(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res), 0, 0,
                           N, Ho, Wo, K, Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1],
-                          pad[0], pad[1], 0, cfg, _lib.stream())
+                          pad[0], pad[1], 0, cfg, 0, _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_conv_igemm(dgrad)")
@@ -164,9 +177,24 @@ class WeightCache:
     only when the parameter has changed (torch version counter or our optimizer's
     generation counter)."""
 
-    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "__weakref__")
+    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "stats", "__weakref__")
+
+    STAT_SLOTS = 64
+
+    def stats_buffer(self, channels: int, device) -> torch.Tensor:
+        """Persistent, zero-on-entry ``[2, STAT_SLOTS, channels]`` accumulator for the BatchNorm
+        statistics the conv epilogue produces (one per device: DataParallel replicas share this object)."""
+        if _STAT_SLOTS_OFF:
+            return None
+        key = (str(device), channels)
+        buf = self.stats.get(key)
+        if buf is None:
+            buf = torch.zeros((2, self.STAT_SLOTS, channels), device=device, dtype=torch.float32)
+            self.stats[key] = buf
+        return buf
 
     def __init__(self):
+        self.stats = {}
         self.pinned_lp = None  # (dtype, tensor, torch version) kept current by the optimizer kernel (amp O2)
         self.key_lp = None
         self.lp = None

@@ -33,7 +33,8 @@ class _ConvBnActFn(torch.autograd.Function):
         K, Cin, R, S = weight.shape
         w_lp = cache.low_precision(weight, dtype)
         train_stats = st.training or st.running_mean is None
-        r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats)
+        sbuf = cache.stats_buffer(K, x.device) if train_stats else None
+        r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats, stats_buf=sbuf)
         if r is None:
             raise RuntimeError(
                 f"conv_bn_act: shape not supported by the MFMA kernels (Cin={Cin}, dtype={dtype}); "
@@ -41,7 +42,9 @@ class _ConvBnActFn(torch.autograd.Function):
         if train_stats:
             y, psum, psq = r
             M = y.numel() // K
-            mean, invstd, scale, shift, count = Nm.finalize(psum, psq, float(M), gamma, beta, st)
+            mean, invstd, scale, shift, count = Nm.finalize(psum, psq, float(M), gamma, beta, st,
+                                                            clear=sbuf is not None
+                                                            and psum.data_ptr() == sbuf.data_ptr())
         else:
             y = r
             scale, shift = Nm.eval_coeffs(gamma, beta, st)
@@ -66,7 +69,7 @@ class _ConvBnActFn(torch.autograd.Function):
         K, Cin, R, S = weight.shape
         if train_stats:
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
-                                           has_res, group, ctx.beta)
+                                           has_res, group, ctx.beta, cache.stats_buffer(K, dout.device))
         else:
             g = dout if not relu else dout * (mask_src > 0).to(dout.dtype)
             dy = (g.float() * scale).to(dout.dtype)

@@ -51,8 +51,11 @@ def stats_partials(y2d: torch.Tensor):
     return part[0], part[1]
 
 
-def finalize(psum, psq, count: float, gamma, beta, st: BNState):
-    """partials -> (mean, invstd, scale, shift); updates running stats in place."""
+def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = False):
+    """partials -> (mean, invstd, scale, shift); updates running stats in place.
+
+    ``clear`` zeroes the partial rows once they have been read (persistent accumulation rows of
+    ``conv.WeightCache.stats_buffer``)."""
     l = _lib.lib()
     C = psum.shape[-1]
     nparts = psum.shape[0]
@@ -62,7 +65,8 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState):
         import torch.distributed as dist
         sums = torch.empty((2 * C,), device=dev, dtype=torch.float32)
         _lib.check(l.pda_bn_reduce_partials(psum.data_ptr(), psq.data_ptr(), nparts, C, sums.data_ptr(),
-                                            _lib.stream()), "pda_bn_reduce_partials")
+                                            int(clear), _lib.stream()), "pda_bn_reduce_partials")
+        clear = False
         dist.all_reduce(sums, group=st.group)
         # every rank of a data-parallel job runs the same per-rank batch, so the global
         # element count is known on the host and no device->host read is needed
@@ -82,7 +86,7 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState):
     _lib.check(l.pda_bn_finalize(psum.data_ptr(), psq.data_ptr(), nparts, C, float(count), float(st.eps),
                                  float(mom if mom is not None else 0.1), _lib.ptr(gamma), _lib.ptr(beta),
                                  _lib.ptr(rm), _lib.ptr(rv), out[0].data_ptr(), out[1].data_ptr(),
-                                 out[2].data_ptr(), out[3].data_ptr(), _lib.ptr(nbt), _lib.stream()),
+                                 out[2].data_ptr(), out[3].data_ptr(), _lib.ptr(nbt), int(clear), _lib.stream()),
                "pda_bn_finalize")
     return out[0], out[1], out[2], out[3], count
 
@@ -118,20 +122,26 @@ def _vec_sink(param):
 
 
 def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu: bool, want_dres: bool,
-             group=None, beta=None):
+             group=None, beta=None, scratch=None):
     """-> dy, dres (or None), dgamma, dbeta.
 
     When both affine parameters opted into direct gradient accumulation, their gradients are added
-    to ``.grad`` by the finalize kernel and ``None`` is returned for them."""
+    to ``.grad`` by the finalize kernel and ``None`` is returned for them.  ``scratch`` (all-zero fp32
+    ``[2, slots, C]``, zero again on return) replaces the per-workgroup partial rows by ``slots``
+    atomically accumulated ones."""
     l = _lib.lib()
     C = y.shape[-1]
     M = y.numel() // C
     dev = y.device
     n = l.pda_bn_num_partials(M, C, _lib.dt(y))
-    part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
+    slots = 0
+    if scratch is not None and n > scratch.shape[1]:
+        part, slots, n = scratch, scratch.shape[1], scratch.shape[1]
+    else:
+        part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
     _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
                                    invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C, int(relu),
-                                   part[0].data_ptr(), part[1].data_ptr(), _lib.stream()), "pda_bn_bwd_reduce")
+                                   part[0].data_ptr(), part[1].data_ptr(), slots, _lib.stream()), "pda_bn_bwd_reduce")
     dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
     coef = torch.empty((5, C), device=dev, dtype=torch.float32)
     sync = _world(group) > 1
@@ -141,7 +151,8 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                                      dgb[1].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                      shift.data_ptr(), _lib.ptr(gamma), float(count),
                                      0 if sync else coef.data_ptr(), sink_g.data_ptr() if direct else 0,
-                                     sink_b.data_ptr() if direct else 0, _lib.stream()), "pda_bn_bwd_finalize")
+                                     sink_b.data_ptr() if direct else 0, int(slots > 0), _lib.stream()),
+               "pda_bn_bwd_finalize")
     if sync:
         import torch.distributed as dist
         tot = dgb.clone()
