@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--batch-size", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch-size", type=int, default=400,
+                    help="per-GPU batch (default 400 = the reference's global -b 3200 over 8 GPUs, "
+                         "/root/reference/2.distributed.py:41-48,113)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--num-classes", type=int, default=1000)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
@@ -42,6 +44,9 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="stock engine only")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
+                         "all-reduce path on a single GPU)")
     return ap.parse_args()
 
 
@@ -56,7 +61,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -79,13 +85,13 @@ def main():
         level = "O0" if args.precision == "fp32" else args.opt_level
         model, opt = amp.initialize(model, opt, opt_level=level, dtype=cdtype if level != "O0" else torch.float16,
                                     verbosity=0)
-        if world > 1:
+        if ddp:
             from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
             model = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb)
         metrics = ops.new_metrics(dev)
 
         def step():
-            model.zero_grad() if world > 1 else opt.zero_grad(set_to_none=False)
+            model.zero_grad() if ddp else opt.zero_grad(set_to_none=False)
             loss = ops.cross_entropy(model(images), target, metrics)
             with amp.scale_loss(loss, opt) as scaled:
                 scaled.backward()
@@ -99,7 +105,7 @@ def main():
             x = images.contiguous(memory_format=torch.channels_last)
         opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
         scaler = torch.amp.GradScaler("cuda", enabled=(cdtype == torch.float16))
-        if world > 1:
+        if ddp:
             model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
         crit = torch.nn.CrossEntropyLoss()
 
@@ -146,7 +152,7 @@ def main():
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
     return 0
 

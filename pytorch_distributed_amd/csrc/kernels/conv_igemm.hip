@@ -447,6 +447,8 @@ struct WgradArgs {
   int R, S, stride_h, stride_w, pad_h, pad_w;
   int M, Ktot;
   int pix_per_split;  // multiple of the pixel step
+  float* slab;        // optional [nsplit][Co][Ktot] scratch: split-K partials stored, not atomically added
+  long long slab_bytes;
 };
 
 template <typename T> struct TrRead;
@@ -525,6 +527,21 @@ wgrad_kernel(WgradArgs a) {
   }
   const int hw = a.Ho * a.Wo;
 
+  // (image, ho, wo) of every pixel row this thread gathers, kept up to date incrementally: a step
+  // moves BKP pixels on, i.e. (dn, dh, dw) with one carry each - no integer division in the loop
+  // (a division costs ~40 VALU instructions; eight of them per step outweighed the step's MFMAs).
+  const int step_n = BKP / hw, step_rem = BKP - step_n * hw;
+  const int step_h = step_rem / a.Wo, step_w = step_rem - step_h * a.Wo;
+  int pn[X_IT], pho[X_IT], pwo[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int m = mbeg + xpx + i * RPX;
+    pn[i] = m / hw;
+    const int rem = m - pn[i] * hw;
+    pho[i] = rem / a.Wo;
+    pwo[i] = rem - pho[i] * a.Wo;
+  }
+
   u32x4 ry[Y_IT], rx[X_IT];
   auto gload = [&](int mstep) {
 #pragma unroll
@@ -542,17 +559,19 @@ wgrad_kernel(WgradArgs a) {
       const int m = mstep + px;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (px < BKP && m < mend && xok_c) {
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        const int hi = ho * a.stride_h - a.pad_h + xr;
-        const int wi = wo * a.stride_w - a.pad_w + xs;
+        const int hi = pho[i] * a.stride_h - a.pad_h + xr;
+        const int wi = pwo[i] * a.stride_w - a.pad_w + xs;
         if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
-          v = *reinterpret_cast<const u32x4*>(X + (long long)n * a.sn + (long long)hi * a.sh +
+          v = *reinterpret_cast<const u32x4*>(X + (long long)pn[i] * a.sn + (long long)hi * a.sh +
                                               (long long)wi * a.sw + xc);
       }
       rx[i] = v;
+      // advance this row by BKP pixels for the next call (calls come in step order)
+      pwo[i] += step_w;
+      if (pwo[i] >= a.Wo) { pwo[i] -= a.Wo; ++pho[i]; }
+      pho[i] += step_h;
+      if (pho[i] >= a.Ho) { pho[i] -= a.Ho; ++pn[i]; }
+      pn[i] += step_n;
     }
   };
   auto lstore = [&](int buf) {
@@ -645,6 +664,24 @@ wgrad_kernel(WgradArgs a) {
     __syncthreads();
   }
 
+  if (a.slab != nullptr) {
+    // split-K partial of this workgroup as plain stores into its own slab (zeros if the split is
+    // empty); wgrad_reduce_kernel sums the slabs into dW afterwards.  Float atomics would move the
+    // same bytes at about a fifth of the store rate.
+    float* __restrict__ sl = a.slab + (long long)blockIdx.y * a.Co * a.Ktot;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = c0n + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = k0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          if (row < a.Co && col < a.Ktot) sl[(long long)row * a.Ktot + col] = acc[i][j][g];
+        }
+      }
+    return;
+  }
   if (nsteps == 0) return;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -657,6 +694,25 @@ wgrad_kernel(WgradArgs a) {
         if (row < a.Co && col < a.Ktot) atomicAdd(a.dw + (long long)row * a.Ktot + col, acc[i][j][g]);
       }
     }
+}
+
+// dw[i] += sum over the nsplit slabs; n is a multiple of 4.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n4, long long n, int nsplit) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(dw + 4 * i);
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {  // four independent 16-byte loads in flight
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(slab + (long long)k * n + 4 * i);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(slab + (long long)(k + 1) * n + 4 * i);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(slab + (long long)(k + 2) * n + 4 * i);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(slab + (long long)(k + 3) * n + 4 * i);
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(slab + (long long)k * n + 4 * i);
+    *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
+  }
 }
 
 // ------------------------------------------------------- weight layouts ----
@@ -805,7 +861,21 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   pps = ((pps + BKP - 1) / BKP) * BKP;
   nsplit = (a.M + pps - 1) / pps;
   a.pix_per_split = pps;
+  // split-K reduction: slabs + one streaming reduce when the caller lent a large enough workspace
+  // (and dW is 16-byte aligned), float atomics straight into dW otherwise
+  const long long n = (long long)a.Co * a.Ktot;
+  // (many splits of a small dW - the 64-channel layers at 56x56 - reduce faster through atomics:
+  // the reduce kernel would walk hundreds of tiny slabs with a handful of workgroups)
+  const bool slabs = nsplit > 1 && nsplit <= 32 && a.slab != nullptr && (long long)nsplit * n * 4 <= a.slab_bytes &&
+                     (n % 4) == 0 && (((uintptr_t)a.dw | (uintptr_t)a.slab) & 15) == 0;
+  if (!slabs) a.slab = nullptr;
   hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+  if (slabs) {
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, a.slab, a.dw, n4, n, nsplit);
+  }
   return pda_check_launch();
 }
 
@@ -813,8 +883,9 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
 PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int Hi, int Wi, int Ci,
                               long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
                               int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int nsplit,
-                              hipStream_t stream) {
+                              float* workspace, long long workspace_bytes, hipStream_t stream) {
   WgradArgs a;
+  a.slab = workspace; a.slab_bytes = workspace_bytes;
   a.dy = dy; a.x = x; a.dw = dw; a.sn = sn; a.sh = sh; a.sw = sw;
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.R = R; a.S = S;
   a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
@@ -830,7 +901,18 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
   if (tile == 0) {
     tile = (Co % 128 == 0 && a.Ktot % 128 == 0) ? 1 : 2;
   }
-  const bool bk32 = (cfg & 8) != 0;
+  bool bk32 = (cfg & 8) != 0;
+  if ((cfg & 7) == 0 && nsplit <= 0 && tile == 1) {
+    // many output tiles and few pixels (layer4-style 3x3): the 32-pixel step needs half the LDS, so
+    // three workgroups fit per CU and ~720 of them run in one round; the 64-pixel one would need two
+    const int tiles = (Co / 128) * (a.Ktot / 128);
+    if (tiles >= 128 && tiles <= 720) {
+      bk32 = true;
+      nsplit = (720 + tiles / 2) / tiles;
+      const int maxsplit = (a.M + 127) / 128;
+      if (nsplit > maxsplit) nsplit = maxsplit;
+    }
+  }
 #define PDA_W16(T)                                                                        \
   if (bk32) {                                                                             \
     if (tile == 1) return launch_wgrad<T, 128, 128, 32>(a, nsplit, stream);               \

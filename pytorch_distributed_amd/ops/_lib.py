@@ -31,8 +31,8 @@ _SIGS = {
     "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
-                       c_i, c_i, c_i, c_i, c_i, c_i, c_p],
-    "pda_krsc_to_crsk": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
+                       c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
+    "pda_krsc_to_crsk":[c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "pda_krsc_to_crsk_batched": [c_i, c_i, c_p, c_p, c_i, c_p],
     "pda_direct_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                         c_i, c_i, c_p],

@@ -113,8 +113,25 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     return dx
 
 
+_WGRAD_WS: dict = {}
+_WGRAD_WS_BYTES = int(os.environ.get("PDA_WGRAD_WORKSPACE_MB", "64")) << 20
+
+
+def _wgrad_workspace(device) -> Optional[torch.Tensor]:
+    """Scratch for the split-K partials of wgrad, one per (device, stream): launches on one stream are
+    ordered, so they can share it.  ``PDA_WGRAD_WORKSPACE_MB=0`` selects the float-atomic reduction."""
+    if _WGRAD_WS_BYTES <= 0:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = torch.empty(_WGRAD_WS_BYTES // 4, device=device, dtype=torch.float32)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
 def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cfg: int = 0, nsplit: int = 0,
-              geom: Optional[tuple] = None, out: Optional[torch.Tensor] = None):
+              geom: Optional[tuple] = None, out: Optional[torch.Tensor] = None, workspace: bool = True):
     """fp32 dW in KRSC layout, shape [K,R,S,C] (accumulates into ``out`` when given)."""
     l = _lib.lib()
     K = dy.shape[-1]
@@ -125,8 +142,10 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
     else:
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
     dw = out if out is not None else torch.zeros((K, R, S, Ci), device=dy.device, dtype=torch.float32)
+    ws = _wgrad_workspace(dy.device) if workspace else None
     rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
-                          Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit, _lib.stream())
+                          Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit,
+                          _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_conv_wgrad")

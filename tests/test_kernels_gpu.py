@@ -122,8 +122,14 @@ def test_wgrad_tiles_and_splits():
     _ref_conv(x, wr, 1, 1).backward(dy.float())
     for cfg in (1, 2, 3, 9, 10, 11):
         for nsplit in (0, 1, 3):
-            dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), cfg=cfg, nsplit=nsplit)
-            assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-2, (cfg, nsplit)
+            for ws in (True, False):  # slab + reduce kernel vs float atomics
+                dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), cfg=cfg, nsplit=nsplit, workspace=ws)
+                assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-2, (cfg, nsplit, ws)
+    # accumulation into an existing gradient
+    base = torch.randn(K, 3, 3, Cin, device=DEV)
+    acc = base.clone()
+    C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), nsplit=5, out=acc)
+    assert rel_err((acc - base).permute(0, 3, 1, 2), wr.grad) < 2e-2
 
 
 def test_batched_weight_transpose_refresh():
@@ -463,6 +469,45 @@ def test_mnist_net_gpu_matches_cpu():
     loss = ops.nll_loss(net(x.to(DEV)), torch.randint(0, 10, (5,), device=DEV))
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_ddp_single_rank_rccl_matches_plain_model(tmp_path):
+    """The bucketed-all-reduce engine on the GPU (RCCL, one rank): gradients accumulated straight into
+    bucket views by the conv / BatchNorm kernels, reduced on the side stream, equal those of the bare
+    model; the optimizer then steps on the bucket views."""
+    import torch.distributed as dist
+    from pytorch_distributed_amd.optim import FusedSGD
+    from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
+                                device_id=torch.device(DEV, 0))
+        created = True
+    try:
+        torch.manual_seed(21)
+        plain = models.get_model("resnet18", num_classes=10).to(DEV)
+        wrapped = models.get_model("resnet18", num_classes=10).to(DEV)
+        wrapped.load_state_dict(plain.state_dict())
+        opt = FusedSGD(wrapped.parameters(), lr=0.05, momentum=0.9)
+        ddp = DDP(wrapped, device_ids=[0], bucket_cap_mb=4.0)
+        x = torch.randn(8, 3, 32, 32, device=DEV)
+        t = torch.randint(0, 10, (8,), device=DEV)
+        F.cross_entropy(plain(x).float(), t).backward()
+        for it in range(2):                      # second pass: direct accumulation into the bucket views
+            ddp.zero_grad()
+            F.cross_entropy(ddp(x).float(), t).backward()
+            torch.cuda.synchronize()
+            gp = dict(plain.named_parameters())
+            for k, p in wrapped.named_parameters():
+                assert p.grad is not None, k
+                assert _cos(p.grad, gp[k].grad) > 0.999, (it, k)
+        before = wrapped.fc.weight.detach().clone()
+        opt.step()
+        assert not torch.equal(before, wrapped.fc.weight)
+        assert all(k.startswith("module.") for k in ddp.state_dict())
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_kernel_library_is_loaded():
