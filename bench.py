@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="stock engine only")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
+    ap.add_argument("--graph", action="store_true",
+                    help="record the step into a hipGraph after warm-up and replay it (single GPU, native engine)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
                          "all-reduce path on a single GPU)")
@@ -123,6 +125,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphed = False
+    if args.graph and args.engine == "native" and not ddp:
+        from pytorch_distributed_amd.utils.graph import GraphedStep
+        eager_step = step
+        step = GraphedStep(eager_step, warmup=min(3, max(args.warmup, 1)))
+        graphed = step.captured
+
     for _ in range(args.warmup):
         loss = step()
     fence()
@@ -139,7 +148,9 @@ def main():
     if rank == 0:
         ips = world * B * args.steps / dt
         out = {
-            "metric": "images/sec (whole node) ResNet-50 fp16 training, synthetic ImageNet 224x224",
+            "metric": ("images/sec (whole node) ResNet-50 fp16 training, synthetic ImageNet 224x224"
+                       if (args.arch, args.precision, S) == ("resnet50", "fp16", 224) else
+                       f"images/sec (whole node) {args.arch} {args.precision} training, synthetic {S}x{S}"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
@@ -148,7 +159,7 @@ def main():
                        "amp_opt_level": args.opt_level if args.precision != "fp32" else "O0",
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
-                       "weights": "random-init", "final_loss": round(final_loss, 4),
+                       "weights": "random-init", "final_loss": round(final_loss, 4), "hip_graph": graphed,
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
         print(json.dumps(out), flush=True)

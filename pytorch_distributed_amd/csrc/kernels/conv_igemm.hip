@@ -38,6 +38,8 @@ struct ConvArgs {
   int relu;
   int Ha, Wb;            // stride-2 dgrad: pixels per parity class along h / w
   int stat_slots;        // 0: psum/psq hold one row per M tile; n > 0: n rows, float-atomic accumulated
+  int r_lo, r_hi, s_lo, s_hi;  // taps that can touch a real pixel for at least one row (host-computed):
+                               // on tiny feature maps (3x3 conv on a 1x1 or 2x2 map) most taps only see padding
 };
 
 // MODE 0: fprop.  MODE 1: dgrad, any power-of-two stride: every tap is visited and rows whose tap
@@ -171,10 +173,12 @@ igemm_kernel(ConvArgs a) {
   }
 
   // taps visited: all of them, or (PAR) those with the parity of this class' pixels
-  const int r0 = PAR ? ((ph + a.pad_h) & 1) : 0, s0 = PAR ? ((pw + a.pad_w) & 1) : 0;
+  // (both restricted to the window of taps that are not pure padding)
+  const int r0 = PAR ? a.r_lo + ((a.r_lo ^ (ph + a.pad_h)) & 1) : a.r_lo;
+  const int s0 = PAR ? a.s_lo + ((a.s_lo ^ (pw + a.pad_w)) & 1) : a.s_lo;
   constexpr int TSTEP = PAR ? 2 : 1;
-  const int nr = PAR ? (a.R > r0 ? (a.R - r0 + 1) >> 1 : 0) : a.R;
-  const int ns = PAR ? (a.S > s0 ? (a.S - s0 + 1) >> 1 : 0) : a.S;
+  const int nr = r0 <= a.r_hi ? (a.r_hi - r0) / TSTEP + 1 : 0;
+  const int ns = s0 <= a.s_hi ? (a.s_hi - s0) / TSTEP + 1 : 0;
 
   u32x4 ra[A_IT], rb[B_IT];
   int r = r0, s = s0, c0 = 0, kofs = (r0 * a.S + s0) * a.Ci;
@@ -227,8 +231,8 @@ igemm_kernel(ConvArgs a) {
     if (c0 >= a.Ci) {
       c0 = 0;
       s += TSTEP;
-      if (s >= a.S) { s = s0; r += TSTEP; }
-      if (PAR) kofs = (r * a.S + s) * a.Ci;
+      if (s > a.s_hi) { s = s0; r += TSTEP; }
+      kofs = (r * a.S + s) * a.Ci;
     }
   };
 
@@ -449,6 +453,7 @@ struct WgradArgs {
   int pix_per_split;  // multiple of the pixel step
   float* slab;        // optional [nsplit][Co][Ktot] scratch: split-K partials stored, not atomically added
   long long slab_bytes;
+  int r_lo, r_hi, s_lo, s_hi;  // taps outside this window only ever multiply padding: their dW stays zero
 };
 
 template <typename T> struct TrRead;
@@ -601,7 +606,16 @@ wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  const int nsteps = (mend > mbeg) ? (mend - mbeg + BKP - 1) / BKP : 0;
+  // a tile whose columns all belong to padding-only taps has nothing to compute
+  bool live = false;
+  {
+    const int last = min(a.Ktot, c0n + TN) - 1;
+    for (int tap = c0n / a.Ci; tap <= last / a.Ci; ++tap) {
+      const int tr = tap / a.S, ts = tap - tr * a.S;
+      live = live || (tr >= a.r_lo && tr <= a.r_hi && ts >= a.s_lo && ts <= a.s_hi);
+    }
+  }
+  const int nsteps = (live && mend > mbeg) ? (mend - mbeg + BKP - 1) / BKP : 0;
   if (nsteps > 0) {
     gload(mbeg);
     lstore(0);
@@ -827,6 +841,20 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
   if (a.M <= 0 || Co <= 0) return 0;
   if (dgrad && (a.sh_log2 < 0 || a.sw_log2 < 0)) return -3;
   if ((long long)N * Ho * Wo > 0x7fffffffLL) return -4;
+  {
+    // taps that reach a real pixel for some output row; fprop: 0 <= ho*stride - pad + r < Hi,
+    // dgrad (Hi = dY height, Ho = dX height): 0 <= h + pad - r <= (Hi-1)*stride
+    long long rl, rh, sl, sh2;
+    if (dgrad) {
+      rl = (long long)pad_h - (long long)(Hi - 1) * stride_h; rh = (long long)Ho - 1 + pad_h;
+      sl = (long long)pad_w - (long long)(Wi - 1) * stride_w; sh2 = (long long)Wo - 1 + pad_w;
+    } else {
+      rl = (long long)pad_h - (long long)(Ho - 1) * stride_h; rh = (long long)Hi - 1 + pad_h;
+      sl = (long long)pad_w - (long long)(Wo - 1) * stride_w; sh2 = (long long)Wi - 1 + pad_w;
+    }
+    a.r_lo = (int)(rl < 0 ? 0 : rl); a.r_hi = (int)(rh > R - 1 ? R - 1 : rh);
+    a.s_lo = (int)(sl < 0 ? 0 : sl); a.s_hi = (int)(sh2 > S - 1 ? S - 1 : sh2);
+  }
   if (dgrad) dgrad = MODE_DGRAD;
   if (dgrad && stride_h == 2 && stride_w == 2 && (cfg & 16) == 0) {  // cfg bit 4 forces the generic path
     dgrad = MODE_DGRAD_S2;
@@ -891,6 +919,12 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
   a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
   a.M = N * Ho * Wo; a.Ktot = R * S * Ci; a.pix_per_split = 0;
   if (a.M <= 0) return 0;
+  {
+    const long long rl = (long long)pad_h - (long long)(Ho - 1) * stride_h, rh = (long long)Hi - 1 + pad_h;
+    const long long sl = (long long)pad_w - (long long)(Wo - 1) * stride_w, sh2 = (long long)Wi - 1 + pad_w;
+    a.r_lo = (int)(rl < 0 ? 0 : rl); a.r_hi = (int)(rh > R - 1 ? R - 1 : rh);
+    a.s_lo = (int)(sl < 0 ? 0 : sl); a.s_hi = (int)(sh2 > S - 1 ? S - 1 : sh2);
+  }
   const int es = dtype == PDA_F32 ? 4 : 2;
   const int epc = 16 / es;
   if (Ci % epc != 0 || Co % epc != 0) return -1;
