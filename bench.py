@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
     ap.add_argument("--graph", action="store_true",
                     help="record the step into a hipGraph after warm-up and replay it (single GPU, native engine)")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="gradient all-reduce through this package's own RCCL communicator instead of torch.distributed")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
                          "all-reduce path on a single GPU)")
@@ -89,7 +91,8 @@ def main():
                                     verbosity=0)
         if ddp:
             from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
-            model = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb)
+            model = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb, force_comm=args.force_ddp,
+                        comm="native" if args.native_comm else None)
         metrics = ops.new_metrics(dev)
 
         def step():

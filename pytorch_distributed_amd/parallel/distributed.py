@@ -35,6 +35,7 @@ and from ``apex.parallel.DistributedDataParallel(model)``
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -70,15 +71,35 @@ class DistributedDataParallel(nn.Module):
                  gradient_as_bucket_view: bool = True, wire_dtype: Optional[torch.dtype] = None,
                  gradient_average: bool = True, gradient_predivide_factor: float = 1.0,
                  delay_allreduce: bool = False, message_size: Optional[int] = None,
-                 rebuild_buckets: bool = True, check_shapes: bool = True, use_avg_op: bool = False):
+                 rebuild_buckets: bool = True, check_shapes: bool = True, use_avg_op: bool = False,
+                 comm=None, force_comm: Optional[bool] = None):
+        """``comm``: collective back-end - ``None`` = the ``torch.distributed`` group ``process_group``
+        (RCCL under backend "nccl"), ``"native"`` = this package's own RCCL communicator
+        (``comm.rccl.RcclCommunicator``, bootstrapped over the existing group), or any object with that
+        interface.  ``force_comm`` (default: env ``PDA_DDP_FORCE_COMM=1``) runs the collectives even
+        for a single rank, which is how the communication path is exercised on a one-GPU machine."""
         super().__init__()
-        if not (dist.is_available() and dist.is_initialized()):
-            raise RuntimeError("DistributedDataParallel needs an initialised process group "
-                               "(pytorch_distributed_amd.comm.init_process_group)")
+        from ..comm.rccl import RcclCommunicator, TorchCollectives
+        if comm is None or comm == "native":
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("DistributedDataParallel needs an initialised process group "
+                                   "(pytorch_distributed_amd.comm.init_process_group)")
+            base = TorchCollectives(process_group)
+            if comm == "native":
+                dev = next(p for p in module.parameters() if p.requires_grad).device
+                comm = RcclCommunicator(base.rank, base.world_size, dev, bootstrap_group=base.group)
+            else:
+                comm = base
+            self.process_group = base.group
+        else:
+            self.process_group = process_group
+        self._coll = comm
         self.module = module
-        self.process_group = process_group if process_group is not None else dist.group.WORLD
-        self.world_size = dist.get_world_size(self.process_group)
-        self.rank = dist.get_rank(self.process_group)
+        self.world_size = comm.world_size
+        self.rank = comm.rank
+        if force_comm is None:
+            force_comm = os.environ.get("PDA_DDP_FORCE_COMM", "0") == "1"
+        self._active = self.world_size > 1 or bool(force_comm)
         self.device_ids = device_ids
         self.output_device = output_device
         self.broadcast_buffers = broadcast_buffers
@@ -88,15 +109,15 @@ class DistributedDataParallel(nn.Module):
         self.predivide = float(gradient_predivide_factor)
         self.delay_allreduce = delay_allreduce
         self.require_backward_grad_sync = True
-        self._rebuild_pending = rebuild_buckets and not delay_allreduce and self.world_size > 1
+        self._rebuild_pending = rebuild_buckets and not delay_allreduce and self._active
         self._params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self._params)}
         if not self._params:
             raise RuntimeError("DistributedDataParallel: module has no parameter that requires grad")
         self.device = self._params[0].device
-        self._backend = dist.get_backend(self.process_group)
+        self._on_device = bool(comm.device_collectives)
         # SUM + one scale pass by default; RCCL's AVG op saves that pass but is opt-in (use_avg_op)
-        self._use_avg_op = (use_avg_op and self._backend == "nccl" and gradient_average and self.predivide == 1.0
+        self._use_avg_op = (use_avg_op and self._on_device and gradient_average and self.predivide == 1.0
                             and wire_dtype is None)
         cap = bucket_cap_mb * _MiB
         first = first_bucket_mb * _MiB
@@ -104,7 +125,7 @@ class DistributedDataParallel(nn.Module):
             cap = first = message_size * self._params[0].element_size()
         if delay_allreduce:
             cap = first = 1 << 62
-        if check_shapes and self.world_size > 1:
+        if check_shapes and self._active:
             self._verify_shapes()
         self._sync_module_states()
         self._callback_queued = False
@@ -124,21 +145,17 @@ class DistributedDataParallel(nn.Module):
     # ------------------------------------------------------------------ construction helpers
     def _verify_shapes(self) -> None:
         sig = torch.tensor([len(self._params)] + [p.numel() for p in self._params], dtype=torch.int64)
-        dev = self.device if self._backend == "nccl" else torch.device("cpu")
+        dev = self.device if self._on_device else torch.device("cpu")
         sig = sig.to(dev)
         ref = sig.clone()
-        dist.broadcast(ref, src=dist.get_global_rank(self.process_group, 0) if hasattr(dist, "get_global_rank") else 0,
-                       group=self.process_group)
+        self._coll.broadcast(ref, 0)
         if ref.shape != sig.shape or not torch.equal(ref, sig):
             raise RuntimeError(f"rank {self.rank}: parameter shapes differ from rank 0's "
                                "(DistributedDataParallel needs identical replicas)")
 
-    def _src(self) -> int:
-        return dist.get_global_rank(self.process_group, 0) if hasattr(dist, "get_global_rank") else 0
-
     def _broadcast_coalesced(self, tensors: List[torch.Tensor]) -> None:
         """rank 0 -> all, one flat buffer per dtype (flatten / unflatten are single launches)."""
-        if self.world_size == 1 or not tensors:
+        if not self._active or not tensors:
             return
         by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
         for t in tensors:
@@ -147,11 +164,11 @@ class DistributedDataParallel(nn.Module):
             if dt.is_floating_point and dt in (torch.float32, torch.float16, torch.bfloat16):
                 flats = [_physical_flat(t.detach()) for t in ts]
                 buf = mt.flatten(flats)
-                dist.broadcast(buf, src=self._src(), group=self.process_group)
+                self._coll.broadcast(buf, 0)
                 mt.unflatten(buf, flats)
             else:
                 buf = torch.cat([t.detach().reshape(-1) for t in ts])
-                dist.broadcast(buf, src=self._src(), group=self.process_group)
+                self._coll.broadcast(buf, 0)
                 off = 0
                 for t in ts:
                     t.detach().copy_(buf[off:off + t.numel()].view_as(t))
@@ -198,7 +215,7 @@ class DistributedDataParallel(nn.Module):
         return ready
 
     def _on_grad_ready(self, i: int, param) -> None:
-        if not self.require_backward_grad_sync or self.world_size == 1:
+        if not self.require_backward_grad_sync or not self._active:
             return
         view = self._view_of[i]
         g = param.grad
@@ -222,14 +239,13 @@ class DistributedDataParallel(nn.Module):
                 bk.wire = torch.empty_like(buf, dtype=self.wire_dtype)
             mt.scale(mt.TensorLists([[buf], [bk.wire]]), 1.0)
             buf = bk.wire
-        op = dist.ReduceOp.AVG if self._use_avg_op else dist.ReduceOp.SUM
-        bk.work = dist.all_reduce(buf, op=op, group=self.process_group, async_op=True)
+        bk.work = self._coll.all_reduce(buf, "avg" if self._use_avg_op else "sum", async_op=True)
         bk.launched = True
 
     def _finalize_backward(self) -> None:
         self._callback_queued = False
         self._in_backward = False
-        if not self.require_backward_grad_sync or self.world_size == 1:
+        if not self.require_backward_grad_sync or not self._active:
             return
         if self._plan.num_unready():
             if not self.find_unused_parameters and not self.delay_allreduce:
@@ -263,16 +279,16 @@ class DistributedDataParallel(nn.Module):
         n = len(self._params)
         t = torch.full((n,), -1, dtype=torch.int64)
         t[:len(order)] = torch.tensor(order, dtype=torch.int64)
-        dev = self.device if self._backend == "nccl" else torch.device("cpu")
+        dev = self.device if self._on_device else torch.device("cpu")
         t = t.to(dev)
-        dist.broadcast(t, src=self._src(), group=self.process_group)
+        self._coll.broadcast(t, 0)
         order = [int(v) for v in t.tolist() if v >= 0]
         self._plan.rebuild(order)
         self._build_buckets()
 
     # ------------------------------------------------------------------ public API
     def forward(self, *inputs, **kwargs):
-        if self.broadcast_buffers and self.training and self.world_size > 1 and torch.is_grad_enabled():
+        if self.broadcast_buffers and self.training and self._active and torch.is_grad_enabled():
             bufs = [b for b in self.module.buffers()]
             if bufs:
                 with torch.no_grad():

@@ -476,10 +476,12 @@ def test_mnist_net_gpu_matches_cpu():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-def test_ddp_single_rank_rccl_matches_plain_model(tmp_path):
-    """The bucketed-all-reduce engine on the GPU (RCCL, one rank): gradients accumulated straight into
-    bucket views by the conv / BatchNorm kernels, reduced on the side stream, equal those of the bare
-    model; the optimizer then steps on the bucket views."""
+@pytest.mark.parametrize("backend", ["torch", "native"])
+def test_ddp_single_rank_rccl_matches_plain_model(tmp_path, backend):
+    """The bucketed-all-reduce engine on the GPU (RCCL, one rank, collectives forced on): gradients
+    accumulated straight into bucket views by the conv / BatchNorm kernels, all-reduced per bucket
+    during backward (through torch.distributed or through this package's own RCCL communicator),
+    equal those of the bare model; the optimizer then steps on the bucket views."""
     import torch.distributed as dist
     from pytorch_distributed_amd.optim import FusedSGD
     from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
@@ -494,7 +496,9 @@ def test_ddp_single_rank_rccl_matches_plain_model(tmp_path):
         wrapped = models.get_model("resnet18", num_classes=10).to(DEV)
         wrapped.load_state_dict(plain.state_dict())
         opt = FusedSGD(wrapped.parameters(), lr=0.05, momentum=0.9)
-        ddp = DDP(wrapped, device_ids=[0], bucket_cap_mb=4.0)
+        ddp = DDP(wrapped, device_ids=[0], bucket_cap_mb=4.0, force_comm=True,
+                  comm="native" if backend == "native" else None)
+        assert ddp._active and len(ddp._buckets) > 1
         x = torch.randn(8, 3, 32, 32, device=DEV)
         t = torch.randint(0, 10, (8,), device=DEV)
         F.cross_entropy(plain(x).float(), t).backward()
@@ -555,6 +559,37 @@ def test_graphed_step_trains(precision):
     assert got[-1] < ref[0]                              # it is learning the fixed batch
     for a, b in zip(got, ref[3:]):
         assert abs(a - b) < 0.15 * max(abs(b), 0.1), (got, ref)
+
+
+def test_native_rccl_communicator_single_rank():
+    """RcclCommunicator (own comm stream + event hand-off) with one rank: every collective is the identity
+    (avg included), asynchronous work objects order the calling stream, health query reports no error."""
+    from pytorch_distributed_amd.comm.rccl import RcclCommunicator
+    c = RcclCommunicator(0, 1, torch.device(DEV, 0))
+    try:
+        x = torch.randn(1 << 20, device=DEV)
+        ref = x.clone()
+        y = x * 2                      # produced on the compute stream right before the collective
+        w = c.all_reduce(y, "sum", async_op=True)
+        w.wait()
+        assert torch.equal(y, ref * 2)
+        h = torch.randn(4097, device=DEV).half()
+        hr = h.clone()
+        c.all_reduce(h, "avg")
+        assert torch.equal(h, hr)
+        b = torch.arange(1000, device=DEV, dtype=torch.int64)
+        c.broadcast(b, 0)
+        assert torch.equal(b, torch.arange(1000, device=DEV))
+        out = torch.empty(333, device=DEV)
+        c.all_gather(out, ref[:333].contiguous())
+        assert torch.equal(out, ref[:333])
+        rs = torch.empty(77, device=DEV)
+        c.reduce_scatter(rs, ref[:77].contiguous())
+        assert torch.equal(rs, ref[:77])
+        c.barrier()
+        assert c.async_error() == 0
+    finally:
+        c.close()
 
 
 def test_kernel_library_is_loaded():
