@@ -57,6 +57,8 @@ def build_parser(description: str = "PyTorch ImageNet Training", arch: str = "re
     p.add_argument("--resume", default="", type=str, metavar="PATH")
     p.add_argument("--steps-per-epoch", default=0, type=int, help="cap iterations per epoch (0 = full)")
     p.add_argument("--jsonl", default="", type=str, help="per-step JSONL log (rank 0)")
+    p.add_argument("--graph", action="store_true",
+                   help="single-GPU runs: record the training step into a hipGraph and replay it")
     p.add_argument("--cpu", action="store_true", help="force CPU + gloo (functional testing)")
     p.add_argument("--exact-eval", action="store_true", help="mask DistributedSampler padding in validation")
     return p
@@ -111,16 +113,20 @@ def train(loader, model, criterion, optimizer, epoch: int, device, args, zero_gr
     nb = len(loader) if not args.steps_per_epoch else min(len(loader), args.steps_per_epoch)
     progress = utils.ProgressMeter(nb, [batch_time, data_time, losses, top1, top5, thr], prefix=f"Epoch: [{epoch}]",
                                    rank0_only=True)
-    metrics = utils.DeviceMetrics(device)
+    # --graph: single-process GPU runs replay the whole step as one hipGraph.  The recorded graph, its
+    # static input buffers and the metric accumulator it writes to live on the optimizer across epochs.
+    use_graph = (getattr(args, "graph", False) and torch.device(device).type == "cuda" and _world() == 1
+                 and _takes_metrics(criterion))
+    gstate = getattr(optimizer, "_pda_graph_state", None) if use_graph else None
+    metrics = gstate["metrics"] if gstate is not None else utils.DeviceMetrics(device)
+    metrics.reset()
+    if use_graph and hasattr(optimizer, "sync_hyperparameters"):
+        optimizer.sync_hyperparameters()  # the epoch's learning rate reaches the replayed kernels
     model.train()
     end = time.time()
     seen = 0
-    for i, (images, target) in enumerate(loader):
-        if i >= nb:
-            break
-        data_time.update(time.time() - end)
-        images = images.to(device, non_blocking=True)
-        target = target.to(device, non_blocking=True)
+
+    def run_step(images, target):
         with utils.annotate("forward"):
             output = model(images)
             loss = criterion(output, target, metrics.buf) if _takes_metrics(criterion) else criterion(output, target)
@@ -135,6 +141,30 @@ def train(loader, model, criterion, optimizer, epoch: int, device, args, zero_gr
                 loss.backward()
         with utils.annotate("step"):
             optimizer.step()
+
+    for i, (images, target) in enumerate(loader):
+        if i >= nb:
+            break
+        data_time.update(time.time() - end)
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        if use_graph and gstate is None:
+            gstate = {"metrics": metrics, "x": images.clone(), "t": target.clone(), "eager": 0, "graph": None}
+            optimizer._pda_graph_state = gstate
+        if gstate is not None and images.shape == gstate["x"].shape and target.shape == gstate["t"].shape:
+            gstate["x"].copy_(images, non_blocking=True)
+            gstate["t"].copy_(target, non_blocking=True)
+            if gstate["graph"] is None and gstate["eager"] >= 3:
+                # three ordinary steps have created every lazily built piece of state: record now
+                gx, gt = gstate["x"], gstate["t"]
+                gstate["graph"] = utils.GraphedStep(lambda: run_step(gx, gt), warmup=0, device=device)
+            if gstate["graph"] is not None:
+                gstate["graph"]()
+            else:
+                run_step(gstate["x"], gstate["t"])
+                gstate["eager"] += 1
+        else:
+            run_step(images, target)
         seen += images.size(0)
         if i % args.print_freq == 0 or i == nb - 1:
             # ONE all-reduce of {loss_sum, correct1, correct5, n}; the only host sync of the window

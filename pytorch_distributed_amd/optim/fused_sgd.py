@@ -127,6 +127,15 @@ class FusedSGD(Optimizer):
             self._hp_host[gi] = host
         return self._hp[gi]
 
+    def sync_hyperparameters(self) -> None:
+        """Push lr / momentum / weight decay of every group to their device tensors now.  ``step`` does
+        this itself; a step replayed from a hipGraph does not run python, so schedulers call this after
+        changing ``param_groups`` (the kernel reads the values from device memory)."""
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.is_cuda]
+            if ps and gi in self._hp:
+                self._group_hp(gi, group, ps[0].device)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

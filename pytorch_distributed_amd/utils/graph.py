@@ -42,7 +42,7 @@ class GraphedStep:
         # Eager runs on the capture stream first: lazily created state (momentum buffers, gradient
         # arena, multi-tensor tables, weight-layout tables, workspaces) must exist before recording.
         with torch.cuda.stream(self._stream):
-            for _ in range(max(int(warmup), 1)):
+            for _ in range(max(int(warmup), 0)):  # 0: the caller has already run the step eagerly
                 fn()
         self._stream.synchronize()
         graph = torch.cuda.CUDAGraph()

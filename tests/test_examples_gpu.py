@@ -1,0 +1,55 @@
+"""Launch-style examples end to end on one MI355X (one rank each: the multi-rank variants run on the
+CPU backends in test_examples_cpu.py), including the hipGraph-replayed training loop."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, "examples")
+COMMON = ["--arch", "resnet18", "--batch-size", "64", "--epochs", "2", "--steps-per-epoch", "8", "--workers", "0",
+          "--num-classes", "10", "-p", "4", "--synthetic"]
+LAUNCH = [sys.executable, "-m", "pytorch_distributed_amd.launch"]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run(cmd, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    return r.stdout
+
+
+def test_style2_ddp_one_gpu_graph_replay(tmp_path):
+    out = run(LAUNCH + ["--nproc_per_node=1", "--master_port", str(free_port()), "--use_argv_local_rank",
+                        os.path.join(EX, "2_distributed.py")] + COMMON + ["--graph"], tmp_path)
+    assert out.count(" * Acc@1") == 2 and "Epoch: [1]" in out
+    assert (tmp_path / "resnet18.checkpoint.pth.tar").exists()
+
+
+def test_style4_amp_one_gpu_graph_replay(tmp_path):
+    out = run(LAUNCH + ["--nproc_per_node=1", "--master_port", str(free_port()), "--use_argv_local_rank",
+                        os.path.join(EX, "4_amp_distributed.py")] + COMMON + ["--graph", "--opt-level", "O2"], tmp_path)
+    assert out.count(" * Acc@1") == 2
+
+
+def test_style3_self_spawn_one_gpu(tmp_path):
+    out = run([sys.executable, os.path.join(EX, "3_multiprocessing_distributed.py")] + COMMON, tmp_path)
+    assert out.count(" * Acc@1") == 2
+
+
+def test_style5_horovod_one_gpu(tmp_path):
+    out = run(LAUNCH + ["-np", "1", "-H", "localhost:1", "--master_port", str(free_port()),
+                        os.path.join(EX, "5_horovod_distributed.py")] + COMMON, tmp_path)
+    assert out.count(" * Acc@1") == 2
