@@ -10,11 +10,14 @@
 Both expose the same small surface: ``rank``, ``world_size``, ``all_reduce(t, op, async_op)``,
 ``broadcast(t, src)``, ``all_gather(out, t)``, ``reduce_scatter(out, t, op)``, ``barrier()``;
 asynchronous calls return a work object whose ``wait()`` orders the *current stream* after the
-collective without blocking the host.
+collective without blocking the host.  The communicator's stream discipline is the usual one: the
+comm stream waits for the producing stream, runs the collective, records an event; consumers wait
+for that event on the device.
 """
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -75,20 +78,22 @@ class TorchCollectives:
 
 
 class _RcclWork:
-    __slots__ = ("comm", "wid", "keep")
+    """Completion of one collective = an event recorded on the comm stream after it."""
+    __slots__ = ("event", "keep", "device")
 
-    def __init__(self, comm: "RcclCommunicator", wid: int, keep):
-        self.comm, self.wid, self.keep = comm, wid, keep
+    def __init__(self, event, keep, device=None):
+        self.event, self.keep, self.device = event, keep, device
 
     def wait(self):
-        if self.wid is not None:
-            self.comm._check(self.comm._l.pda_rccl_wait(self.comm._h, self.wid, _lib.stream()), "wait")
-            self.wid = None
+        if self.event is not None:
+            # device-side ordering, the host does not block
+            torch.cuda.current_stream(self.device).wait_event(self.event)
+            self.event = None
             self.keep = None
         return True
 
     def is_completed(self) -> bool:
-        return self.wid is None or self.comm._l.pda_rccl_query(self.comm._h, self.wid) != 0
+        return self.event is None or self.event.query()
 
 
 def _bind(l):
@@ -101,14 +106,10 @@ def _bind(l):
         "pda_rccl_create": ([c_p, c_i, c_i, c_i], c_p),
         "pda_rccl_destroy": ([c_p], None),
         "pda_rccl_last_error": ([c_p], ctypes.c_char_p),
-        "pda_rccl_stream": ([c_p], c_p),
-        "pda_rccl_all_reduce": ([c_p, c_p, c_p, c_ll, c_i, c_i, c_p], c_ll),
-        "pda_rccl_broadcast": ([c_p, c_p, c_ll, c_i, c_i, c_p], c_ll),
-        "pda_rccl_all_gather": ([c_p, c_p, c_p, c_ll, c_i, c_p], c_ll),
-        "pda_rccl_reduce_scatter": ([c_p, c_p, c_p, c_ll, c_i, c_i, c_p], c_ll),
-        "pda_rccl_wait": ([c_p, c_ll, c_p], c_i),
-        "pda_rccl_query": ([c_p, c_ll], c_i),
-        "pda_rccl_synchronize": ([c_p], c_i),
+        "pda_rccl_all_reduce": ([c_p, c_p, c_p, c_ll, c_i, c_i, c_p], c_i),
+        "pda_rccl_broadcast": ([c_p, c_p, c_ll, c_i, c_i, c_p], c_i),
+        "pda_rccl_all_gather": ([c_p, c_p, c_p, c_ll, c_i, c_p], c_i),
+        "pda_rccl_reduce_scatter": ([c_p, c_p, c_p, c_ll, c_i, c_i, c_p], c_i),
         "pda_rccl_async_error": ([c_p], c_i),
         "pda_rccl_abort": ([c_p], c_i),
     }
@@ -129,7 +130,7 @@ class RcclCommunicator:
     """
 
     def __init__(self, rank: int, world_size: int, device: Optional[torch.device] = None, store=None,
-                 bootstrap_group=None, key: str = "pda/rccl_uid"):
+                 bootstrap_group=None, key: str = "pda/rccl_uid", overlap: Optional[bool] = None):
         self._l = _bind(_lib.lib())
         if not self._l.pda_rccl_available():
             raise RuntimeError("RCCL could not be loaded (librccl.so)")
@@ -162,6 +163,16 @@ class RcclCommunicator:
         if not self._h:
             raise RuntimeError("ncclCommInitRank failed")
         self.backend = "rccl-native"
+        # dedicated high-priority stream: collectives overtake queued compute kernels where the
+        # hardware allows and never serialise behind the backward pass they overlap with
+        self.stream = torch.cuda.Stream(device=self.device, priority=-1)
+        # overlap=False (default): a collective is the next operation of the caller's stream - no
+        # cross-stream dependency at all.  overlap=True (or PDA_RCCL_OVERLAP=1) runs it on the comm
+        # stream above so it overlaps with compute; with the HIP runtime of this image that mode was
+        # seen to stall when collectives are enqueued from an autograd worker thread that existed
+        # before the communicator (pure event chain, single rank), so it is opt-in.  The
+        # torch.distributed back-end (TorchCollectives) always overlaps.
+        self.overlap = os.environ.get("PDA_RCCL_OVERLAP", "0") == "1" if overlap is None else bool(overlap)
 
     # -- helpers ----------------------------------------------------------------------------
     def _check(self, rc, what: str) -> None:
@@ -178,9 +189,20 @@ class RcclCommunicator:
             raise TypeError(f"unsupported dtype {t.dtype}")
         return t
 
-    def _finish(self, wid: int, async_op: bool, keep):
-        self._check(wid, "enqueue")
-        w = _RcclWork(self, wid, keep)
+    def _run(self, call, async_op: bool, keep):
+        """comm stream waits for the caller's stream, runs ``call(stream_handle)``, records completion."""
+        cur = torch.cuda.current_stream(self.device)
+        if not self.overlap:
+            # in-order mode: the collective is simply the next operation of the caller's stream
+            self._check(call(cur.cuda_stream), "collective")
+            return _DoneWork() if async_op else None
+        self.stream.wait_stream(cur)
+        self._check(call(self.stream.cuda_stream), "collective")
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        for t in (keep if isinstance(keep, tuple) else (keep,)):
+            t.record_stream(self.stream)   # the allocator must not recycle the buffer under the collective
+        w = _RcclWork(ev, keep, self.device)
         if async_op:
             return w
         w.wait()
@@ -189,33 +211,31 @@ class RcclCommunicator:
     # -- collectives ------------------------------------------------------------------------
     def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
         t = self._prep(t)
-        wid = self._l.pda_rccl_all_reduce(self._h, t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], _OPS[op],
-                                          _lib.stream())
-        return self._finish(wid, async_op, t)
+        return self._run(lambda s: self._l.pda_rccl_all_reduce(self._h, t.data_ptr(), t.data_ptr(), t.numel(),
+                                                               _DT[t.dtype], _OPS[op], s), async_op, t)
 
     def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
         t = self._prep(t)
-        wid = self._l.pda_rccl_broadcast(self._h, t.data_ptr(), t.numel(), _DT[t.dtype], int(src), _lib.stream())
-        return self._finish(wid, async_op, t)
+        return self._run(lambda s: self._l.pda_rccl_broadcast(self._h, t.data_ptr(), t.numel(), _DT[t.dtype],
+                                                              int(src), s), async_op, t)
 
     def all_gather(self, out: torch.Tensor, t: torch.Tensor, async_op: bool = False):
         t, out = self._prep(t), self._prep(out)
         assert out.numel() == t.numel() * self.world_size and out.dtype == t.dtype
-        wid = self._l.pda_rccl_all_gather(self._h, t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], _lib.stream())
-        return self._finish(wid, async_op, (t, out))
+        return self._run(lambda s: self._l.pda_rccl_all_gather(self._h, t.data_ptr(), out.data_ptr(), t.numel(),
+                                                               _DT[t.dtype], s), async_op, (t, out))
 
     def reduce_scatter(self, out: torch.Tensor, t: torch.Tensor, op: str = "sum", async_op: bool = False):
         t, out = self._prep(t), self._prep(out)
         assert t.numel() == out.numel() * self.world_size and out.dtype == t.dtype
-        wid = self._l.pda_rccl_reduce_scatter(self._h, t.data_ptr(), out.data_ptr(), out.numel(), _DT[t.dtype],
-                                              _OPS[op], _lib.stream())
-        return self._finish(wid, async_op, (t, out))
+        return self._run(lambda s: self._l.pda_rccl_reduce_scatter(self._h, t.data_ptr(), out.data_ptr(), out.numel(),
+                                                                   _DT[t.dtype], _OPS[op], s), async_op, (t, out))
 
     def barrier(self) -> None:
         """All ranks have reached this point AND their previously enqueued device work is done."""
         flag = torch.zeros(1, device=self.device, dtype=torch.float32)
         self.all_reduce(flag)
-        self._check(self._l.pda_rccl_synchronize(self._h), "synchronize")
+        self.stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
 
     # -- health -----------------------------------------------------------------------------
@@ -228,6 +248,10 @@ class RcclCommunicator:
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            try:
+                self.stream.synchronize()
+            except Exception:
+                pass
             self._l.pda_rccl_destroy(self._h)
             self._h = None
 

@@ -231,7 +231,9 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 
 // g = dout masked by the ReLU of the forward (mask from `out` when given, else
 // recomputed from y*scale+shift which is exact when there was no residual).
-template <typename T>
+// MASK (compile time, so that no load sits behind a run-time branch): 0 = no ReLU, 1 = mask
+// recomputed from y, 2 = mask read from `out`.
+template <typename T, int MASK>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                      const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -241,16 +243,20 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
   __shared__ float red[2][256 * EPC];
   ColGeom<T> g(C, blockIdx.y);
   const int vpr = C / EPC;
-  float dg[EPC], db[EPC], mu[EPC], is[EPC], sc[EPC], sf[EPC];
+  // The loop accumulates sum(g) and sum(g*y) only; sum(g*xhat) = invstd * (sum(g*y) - mean*sum(g)) is
+  // formed once per workgroup at the end, which keeps mean/invstd out of the loop's registers
+  // (the kernel is bandwidth-bound and lives on occupancy).
+  float dg[EPC], db[EPC], sc[EPC], sf[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; sc[e] = 0.f; sf[e] = 0.f; }
+  for (int e = 0; e < EPC; ++e) { dg[e] = 0.f; db[e] = 0.f; sc[e] = 0.f; sf[e] = 0.f; }
+  (void)relu;
   if (g.vec < vpr) {
+    if (MASK == 1) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      mu[e] = mean[g.vec * EPC + e];
-      is[e] = invstd[g.vec * EPC + e];
-      sc[e] = scale[g.vec * EPC + e];
-      sf[e] = shift[g.vec * EPC + e];
+      for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale[g.vec * EPC + e];
+        sf[e] = shift[g.vec * EPC + e];
+      }
     }
     const long long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
     const long long r0 = blockIdx.x * rows_per_blk;
@@ -260,15 +266,13 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
       for (int e = 0; e < EPC; ++e) {
         float gd = ElemTraits<T>::to_f32(vd.v[e]);
         const float yv = ElemTraits<T>::to_f32(vy.v[e]);
-        if (relu) {
-          const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * sc[e] + sf[e] > 0.f);
-          gd = pos ? gd : 0.f;
-        }
+        if (MASK == 2) gd = ElemTraits<T>::to_f32(vo.v[e]) > 0.f ? gd : 0.f;
+        if (MASK == 1) gd = (yv * sc[e] + sf[e] > 0.f) ? gd : 0.f;
         db[e] += gd;
-        dg[e] += gd * (yv - mu[e]) * is[e];
+        dg[e] += gd * yv;
       }
     };
-    const bool need_out = relu && out;
+    constexpr bool need_out = MASK == 2;
     long long r = r0 + g.rl;
     // four rows in flight per thread: the loop is latency-bound otherwise
     for (; r + 3 * g.RS < r1; r += 4 * g.RS) {
@@ -324,6 +328,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
         a += red[0][(w * 64 + l) * EPC + e];
         b += red[1][(w * 64 + l) * EPC + e];
       }
+      a = invstd[g.vec * EPC + e] * (a - mean[g.vec * EPC + e] * b);
       if (slots > 0) {  // pre-zeroed accumulation rows shared by many workgroups
         atomicAdd(pdg + (long long)(blockIdx.x % slots) * C + g.vec * EPC + e, a);
         atomicAdd(pdb + (long long)(blockIdx.x % slots) * C + g.vec * EPC + e, b);
@@ -534,10 +539,16 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0) return -1;
   const int nb = pda_bn_num_partials(M, C, dtype);
-  PDA_DISPATCH_T(dtype,
-                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256), 0, st,
-                                    (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift, M, C,
-                                    relu, pdg, pdb, slots));
+  const int mask = !relu ? 0 : (out ? 2 : 1);
+#define PDA_BWD_REDUCE(MASK)                                                                                  \
+  PDA_DISPATCH_T(dtype,                                                                                       \
+                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3(nb, col_blocks_y(C, es)), dim3(256), \
+                                    0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale,   \
+                                    shift, M, C, relu, pdg, pdb, slots))
+  if (mask == 0) { PDA_BWD_REDUCE(0); }
+  else if (mask == 1) { PDA_BWD_REDUCE(1); }
+  else { PDA_BWD_REDUCE(2); }
+#undef PDA_BWD_REDUCE
   return pda_check_launch();
 }
 

@@ -3,11 +3,12 @@
 // (reference: `dist.init_process_group(backend='nccl')` + `dist.all_reduce` / `dist.barrier`,
 // /root/reference/2.distributed.py:98,73,219; ProcessGroupNCCL there).
 //
-// One communicator = one RCCL comm + one dedicated high-priority HIP stream.  A collective is
-// enqueued as  record(event on the caller's compute stream) -> comm stream waits for it -> RCCL call
-// on the comm stream -> record(done event); `wait` makes a compute stream wait for the done event
-// on the device, without blocking the host, so gradient buckets overlap with the rest of backward.
-// The 128-byte unique id travels through the rendezvous store (python side).
+// This file owns the RCCL communicator (unique id, ncclCommInitRank, the collective calls, async
+// error query / abort); comm/rccl.py owns the stream discipline around it: a dedicated high-priority
+// comm stream that waits for the producing compute stream, runs the collective and records an event
+// the consumer stream later waits on - on the device, without blocking the host, so gradient
+// buckets overlap with the rest of backward.  The 128-byte unique id travels through the rendezvous
+// store (python side).
 //
 // RCCL is resolved with dlopen at first use, after PyTorch has loaded its own copy, so the process
 // ends up with a single RCCL instance whichever library provides it.
@@ -95,23 +96,8 @@ bool to_nccl_op(int op, ncclRedOp_t* out) {  // SUM, PROD, MIN, MAX, AVG: the co
 
 struct Comm {
   ncclComm_t comm = nullptr;
-  hipStream_t stream = nullptr;
   int device = 0, rank = 0, world = 1;
-  std::mutex mu;
-  std::vector<hipEvent_t> free_events;
-  std::vector<hipEvent_t> works;  // work id -> done event (null once released)
   std::string last_error;
-
-  hipEvent_t get_event() {
-    if (!free_events.empty()) {
-      hipEvent_t e = free_events.back();
-      free_events.pop_back();
-      return e;
-    }
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    return e;
-  }
 };
 
 int fail(Comm* c, const std::string& what) {
@@ -119,33 +105,16 @@ int fail(Comm* c, const std::string& what) {
   return -1;
 }
 
-// Order the comm stream after `compute`, run fn on it, hand back a work id.
+// Run one RCCL call on `stream` with the communicator's device current.
 template <typename F>
-long long enqueue(Comm* c, hipStream_t compute, F&& fn) {
-  std::lock_guard<std::mutex> g(c->mu);
+int run_on(Comm* c, F&& fn) {
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return fail(c, "hipGetDevice failed");
   if (prev != c->device && hipSetDevice(c->device) != hipSuccess) return fail(c, "hipSetDevice failed");
-  long long id = -1;
-  hipEvent_t ready = c->get_event(), done = c->get_event();
-  do {
-    if (!ready || !done) { fail(c, "hipEventCreate failed"); break; }
-    if (hipEventRecord(ready, compute) != hipSuccess) { fail(c, "hipEventRecord failed"); break; }
-    if (hipStreamWaitEvent(c->stream, ready, 0) != hipSuccess) { fail(c, "hipStreamWaitEvent failed"); break; }
-    const ncclResult_t r = fn(c->stream);
-    if (r != ncclSuccess) {
-      fail(c, std::string("RCCL: ") + api().GetErrorString(r));
-      break;
-    }
-    if (hipEventRecord(done, c->stream) != hipSuccess) { fail(c, "hipEventRecord failed"); break; }
-    c->works.push_back(done);
-    id = (long long)c->works.size() - 1;
-    done = nullptr;
-  } while (false);
-  if (ready) c->free_events.push_back(ready);  // safe to reuse: stream-ordered record/wait pairs
-  if (done) c->free_events.push_back(done);
+  const ncclResult_t r = fn();
   if (prev != c->device) (void)hipSetDevice(prev);
-  return id;
+  if (r != ncclSuccess) return fail(c, std::string("RCCL: ") + api().GetErrorString(r));
+  return 0;
 }
 
 }  // namespace
@@ -171,107 +140,64 @@ PDA_EXPORT void* pda_rccl_create(const char* id128, int rank, int world, int dev
   c->device = device; c->rank = rank; c->world = world;
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
-  int lo = 0, hi = 0;
-  bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi) == hipSuccess &&
-            a.CommInitRank(&c->comm, world, id, rank) == ncclSuccess;
+  const bool ok = a.CommInitRank(&c->comm, world, id, rank) == ncclSuccess;
   (void)hipSetDevice(prev);
   if (!ok) {
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return nullptr;
   }
   return c;
 }
 
+// The caller has drained the streams it used with this communicator.
 PDA_EXPORT void pda_rccl_destroy(void* h) {
   Comm* c = static_cast<Comm*>(h);
   if (!c) return;
   int prev = 0;
   (void)hipGetDevice(&prev);
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
   if (c->comm) api().CommDestroy(c->comm);
-  for (hipEvent_t e : c->works) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(c->stream);
   (void)hipSetDevice(prev);
   delete c;
 }
 
 PDA_EXPORT const char* pda_rccl_last_error(void* h) { return static_cast<Comm*>(h)->last_error.c_str(); }
-PDA_EXPORT void* pda_rccl_stream(void* h) { return static_cast<Comm*>(h)->stream; }
 
-PDA_EXPORT long long pda_rccl_all_reduce(void* h, const void* send, void* recv, long long count, int dtype, int op,
-                                         hipStream_t compute) {
+PDA_EXPORT int pda_rccl_all_reduce(void* h, const void* send, void* recv, long long count, int dtype, int op,
+                                   hipStream_t stream) {
   Comm* c = static_cast<Comm*>(h);
   ncclDataType_t dt; ncclRedOp_t ro;
   if (!to_nccl_dtype(dtype, &dt) || !to_nccl_op(op, &ro) || count < 0) return fail(c, "bad dtype/op/count");
-  return enqueue(c, compute, [&](hipStream_t s) { return api().AllReduce(send, recv, (size_t)count, dt, ro, c->comm, s); });
+  return run_on(c, [&] { return api().AllReduce(send, recv, (size_t)count, dt, ro, c->comm, stream); });
 }
 
-PDA_EXPORT long long pda_rccl_broadcast(void* h, void* buf, long long count, int dtype, int root, hipStream_t compute) {
+PDA_EXPORT int pda_rccl_broadcast(void* h, void* buf, long long count, int dtype, int root, hipStream_t stream) {
   Comm* c = static_cast<Comm*>(h);
   ncclDataType_t dt;
   if (!to_nccl_dtype(dtype, &dt) || root < 0 || root >= c->world || count < 0) return fail(c, "bad dtype/root/count");
-  return enqueue(c, compute, [&](hipStream_t s) { return api().Broadcast(buf, buf, (size_t)count, dt, root, c->comm, s); });
+  return run_on(c, [&] { return api().Broadcast(buf, buf, (size_t)count, dt, root, c->comm, stream); });
 }
 
-PDA_EXPORT long long pda_rccl_all_gather(void* h, const void* send, void* recv, long long count_per_rank, int dtype,
-                                         hipStream_t compute) {
+PDA_EXPORT int pda_rccl_all_gather(void* h, const void* send, void* recv, long long count_per_rank, int dtype,
+                                   hipStream_t stream) {
   Comm* c = static_cast<Comm*>(h);
   ncclDataType_t dt;
   if (!to_nccl_dtype(dtype, &dt) || count_per_rank < 0) return fail(c, "bad dtype/count");
-  return enqueue(c, compute,
-                 [&](hipStream_t s) { return api().AllGather(send, recv, (size_t)count_per_rank, dt, c->comm, s); });
+  return run_on(c, [&] { return api().AllGather(send, recv, (size_t)count_per_rank, dt, c->comm, stream); });
 }
 
-PDA_EXPORT long long pda_rccl_reduce_scatter(void* h, const void* send, void* recv, long long count_per_rank, int dtype,
-                                             int op, hipStream_t compute) {
+PDA_EXPORT int pda_rccl_reduce_scatter(void* h, const void* send, void* recv, long long count_per_rank, int dtype,
+                                       int op, hipStream_t stream) {
   Comm* c = static_cast<Comm*>(h);
   ncclDataType_t dt; ncclRedOp_t ro;
   if (!to_nccl_dtype(dtype, &dt) || !to_nccl_op(op, &ro) || count_per_rank < 0) return fail(c, "bad dtype/op/count");
-  return enqueue(c, compute, [&](hipStream_t s) {
-    return api().ReduceScatter(send, recv, (size_t)count_per_rank, dt, ro, c->comm, s);
-  });
-}
-
-// Make `compute` wait (on the device) for work `id`; release its event.
-PDA_EXPORT int pda_rccl_wait(void* h, long long id, hipStream_t compute) {
-  Comm* c = static_cast<Comm*>(h);
-  std::lock_guard<std::mutex> g(c->mu);
-  if (id < 0 || id >= (long long)c->works.size() || !c->works[(size_t)id]) return fail(c, "unknown work id");
-  hipEvent_t e = c->works[(size_t)id];
-  if (hipStreamWaitEvent(compute, e, 0) != hipSuccess) return fail(c, "hipStreamWaitEvent failed");
-  c->works[(size_t)id] = nullptr;
-  c->free_events.push_back(e);
-  // compact the table once everything issued so far has been waited for
-  bool all_free = true;
-  for (hipEvent_t w : c->works) all_free = all_free && !w;
-  if (all_free) c->works.clear();
-  return 0;
-}
-
-// 1 = finished, 0 = still running, <0 = error.  Does not release the work.
-PDA_EXPORT int pda_rccl_query(void* h, long long id) {
-  Comm* c = static_cast<Comm*>(h);
-  std::lock_guard<std::mutex> g(c->mu);
-  if (id < 0 || id >= (long long)c->works.size() || !c->works[(size_t)id]) return 1;
-  const hipError_t r = hipEventQuery(c->works[(size_t)id]);
-  if (r == hipSuccess) return 1;
-  if (r == hipErrorNotReady) return 0;
-  return fail(c, "hipEventQuery failed");
-}
-
-// Host-blocking completion of everything enqueued so far (barrier semantics need it).
-PDA_EXPORT int pda_rccl_synchronize(void* h) {
-  Comm* c = static_cast<Comm*>(h);
-  return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : fail(c, "hipStreamSynchronize failed");
+  return run_on(c, [&] { return api().ReduceScatter(send, recv, (size_t)count_per_rank, dt, ro, c->comm, stream); });
 }
 
 // Watchdog support: 0 = healthy, >0 = RCCL async error code.
 PDA_EXPORT int pda_rccl_async_error(void* h) {
   Comm* c = static_cast<Comm*>(h);
+  if (!c->comm) return -1;
   ncclResult_t st = ncclSuccess;
   if (api().CommGetAsyncError(c->comm, &st) != ncclSuccess) return -1;
   return (int)st;

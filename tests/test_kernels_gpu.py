@@ -561,11 +561,13 @@ def test_graphed_step_trains(precision):
         assert abs(a - b) < 0.15 * max(abs(b), 0.1), (got, ref)
 
 
-def test_native_rccl_communicator_single_rank():
-    """RcclCommunicator (own comm stream + event hand-off) with one rank: every collective is the identity
-    (avg included), asynchronous work objects order the calling stream, health query reports no error."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_native_rccl_communicator_single_rank(overlap):
+    """RcclCommunicator (in-order, or own comm stream + event hand-off) with one rank: every collective is
+    the identity (avg included), asynchronous work objects order the calling stream, health query reports
+    no error."""
     from pytorch_distributed_amd.comm.rccl import RcclCommunicator
-    c = RcclCommunicator(0, 1, torch.device(DEV, 0))
+    c = RcclCommunicator(0, 1, torch.device(DEV, 0), overlap=overlap)
     try:
         x = torch.randn(1 << 20, device=DEV)
         ref = x.clone()
