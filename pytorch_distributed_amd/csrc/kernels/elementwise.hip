@@ -59,6 +59,43 @@ add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, 
     o[i] = ElemTraits<T>::from_f32(v);
   }
 }
+// out = sum of up to 8 same-sized buffers in one pass (DataParallel's reduce-add of per-replica
+// gradients: one read of every replica's flat gradient instead of N-1 read-modify-write passes).
+struct AddNArgs {
+  const void* src[8];
+  int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_n_kernel(AddNArgs a, T* __restrict__ o, long long nvec, long long count) {
+  constexpr int EPC = 16 / sizeof(T);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < a.n) {
+        const Vec16<T> v = load16(reinterpret_cast<const T*>(a.src[s]) + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += ElemTraits<T>::to_f32(v.v[e]);
+      }
+    }
+    Vec16<T> r;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) r.v[e] = ElemTraits<T>::from_f32(acc[e]);
+    store16(o + i * EPC, r);
+  }
+  // tail (count not a multiple of the vector width): first workgroup, scalar
+  if (blockIdx.x == 0) {
+    for (long long i = nvec * EPC + threadIdx.x; i < count; i += blockDim.x) {
+      float acc = 0.f;
+      for (int s = 0; s < a.n; ++s) acc += ElemTraits<T>::to_f32(reinterpret_cast<const T*>(a.src[s])[i]);
+      o[i] = ElemTraits<T>::from_f32(acc);
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 bias_add_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, long long n, int C,
@@ -167,6 +204,24 @@ PDA_EXPORT int pda_relu_bwd(int dtype, const void* dy, const void* y, void* dx, 
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n));
   return pda_check_launch();
 }
+// srcs: array of nsrc (<= 8) device pointers, all 16-byte aligned like out; out may alias srcs[0].
+PDA_EXPORT int pda_add_n(int dtype, const void* const* srcs, int nsrc, void* out, long long count, hipStream_t st) {
+  if (nsrc < 1 || nsrc > 8) return -1;
+  if (count <= 0) return 0;
+  AddNArgs a;
+  a.n = nsrc;
+  for (int i = 0; i < 8; ++i) {
+    a.src[i] = i < nsrc ? srcs[i] : nullptr;
+    if (i < nsrc && ((uintptr_t)srcs[i] & 15)) return -5;
+  }
+  if ((uintptr_t)out & 15) return -5;
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  const long long nvec = count / (16 / es);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((add_n_kernel<T>), dim3(ew_blocks(nvec > 0 ? nvec : 1)), dim3(256), 0, st, a,
+                                           (T*)out, nvec, count));
+  return pda_check_launch();
+}
+
 PDA_EXPORT int pda_add(int dtype, const void* a, const void* b, void* o, long long n, int relu, hipStream_t st) {
   if (n == 0) return 0;
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)a, (const T*)b, (T*)o, n, relu));

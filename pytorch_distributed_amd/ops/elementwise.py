@@ -86,3 +86,28 @@ def dropout2d(x: torch.Tensor, p: float = 0.5, training: bool = True) -> torch.T
     if not x.is_cuda:
         return F.dropout2d(x.permute(0, 3, 1, 2), p, True).permute(0, 2, 3, 1).contiguous()
     return _DropoutFn.apply(x, p, True)
+
+
+def add_n(tensors, out: torch.Tensor = None) -> torch.Tensor:
+    """Sum of up to 8 same-shaped dense tensors in one pass (``out`` may be ``tensors[0]``).
+    GPU: one launch of ``add_n_kernel``; CPU: plain adds.  No autograd."""
+    import ctypes
+    ts = list(tensors)
+    assert ts and all(t.shape == ts[0].shape and t.dtype == ts[0].dtype and t.device == ts[0].device for t in ts)
+    if out is None:
+        out = torch.empty_like(ts[0])
+    if not ts[0].is_cuda:
+        acc = ts[0].clone() if out is not ts[0] else ts[0]
+        for t in ts[1:]:
+            acc = acc.add_(t) if acc is ts[0] and out is ts[0] else acc + t
+        if out is not acc:
+            out.copy_(acc)
+        return out
+    while len(ts) > 8:  # fold in groups of 8
+        head = add_n(ts[:8])
+        ts = [head] + ts[8:]
+    ts = [t if t.is_contiguous() else t.contiguous() for t in ts]
+    l = _lib.lib()
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    _lib.check(l.pda_add_n(_lib.dt(ts[0]), arr, len(ts), out.data_ptr(), ts[0].numel(), _lib.stream()), "pda_add_n")
+    return out

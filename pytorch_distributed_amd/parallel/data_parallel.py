@@ -142,10 +142,16 @@ def reduce_add_coalesced(per_device: Sequence[Sequence[torch.Tensor]], target) -
     n = len(per_device[0])
     first = [t if t.device == target else t.to(target) for t in per_device[0]]
     acc = mt.flatten([t.reshape(-1) if t.is_contiguous() else _physical_flat(t) for t in first])
+    flats = []
     for lst in per_device[1:]:
         flat = mt.flatten([t.reshape(-1) if t.is_contiguous() else _physical_flat(t) for t in lst])
-        flat = flat.to(target, non_blocking=True)
-        mt.axpby(mt.TensorLists([[acc], [flat], [acc]]), 1.0, 1.0)
+        flats.append(flat.to(target, non_blocking=True))   # one peer copy per replica (xGMI)
+    if flats and acc.is_cuda and acc.dtype in (torch.float32, torch.float16, torch.bfloat16):
+        from ..ops.elementwise import add_n
+        add_n([acc] + flats, out=acc)                        # N-way reduce-add: every buffer is read once
+    else:
+        for flat in flats:
+            mt.axpby(mt.TensorLists([[acc], [flat], [acc]]), 1.0, 1.0)
     res, off = [], 0
     for t in first:
         if _is_dense(t):

@@ -594,6 +594,26 @@ def test_native_rccl_communicator_single_rank(overlap):
         c.close()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_add_n_and_dataparallel_reduce_add(dtype):
+    from pytorch_distributed_amd.ops.elementwise import add_n
+    from pytorch_distributed_amd.parallel.data_parallel import reduce_add_coalesced
+    torch.manual_seed(51)
+    ts = [torch.randn(100003, device=DEV).to(dtype) for _ in range(5)]
+    ref = sum(t.float() for t in ts)
+    assert rel_err(add_n(ts), ref) < (1e-6 if dtype == torch.float32 else 2e-3)
+    acc = ts[0].clone()
+    add_n([acc] + ts[1:], out=acc)                      # in place over the first operand
+    assert rel_err(acc, ref) < (1e-6 if dtype == torch.float32 else 2e-3)
+    many = [torch.randn(4099, device=DEV) for _ in range(11)]   # more than one kernel's worth of sources
+    assert rel_err(add_n(many), sum(many)) < 1e-5
+    # three "replicas" (all on this GPU) of a two-tensor gradient list, one of them channels-last
+    per_dev = [[torch.randn(8, 4, 3, 3, device=DEV).to(memory_format=torch.channels_last), torch.randn(17, device=DEV)]
+               for _ in range(3)]
+    out = reduce_add_coalesced(per_dev, DEV)
+    assert rel_err(out[0], sum(p[0] for p in per_dev)) < 1e-5 and rel_err(out[1], sum(p[1] for p in per_dev)) < 1e-5
+
+
 def test_kernel_library_is_loaded():
     _lib.lib()
     maps = open("/proc/self/maps").read()
