@@ -12,8 +12,10 @@ One tool for the reference's three external launch styles:
   so the same command line works on every node (/root/reference/6.distributed_slurm_main.py:89-94).
 
 Failure handling: the first child that exits non-zero gets its siblings terminated and its exit
-code becomes the launcher's.  Each rank is pinned to one GPU through HIP_VISIBLE_DEVICES unless
-``--no_pin`` is given.
+code becomes the launcher's.  Every rank still sees all GPUs (RCCL's intra-node peer access and
+``LOCAL_RANK``-based ``set_device`` both need that); unless ``--no_pin`` is given the launcher also
+exports ``PDA_ASSIGNED_DEVICE`` = the entry of ``HIP_VISIBLE_DEVICES`` (or the ordinal) meant for
+this local rank, for scripts that prefer an explicit assignment.
 """
 from __future__ import annotations
 
@@ -36,7 +38,7 @@ def parse(argv=None):
     ap.add_argument("--master_port", "--master-port", type=int, default=None)
     ap.add_argument("--use_argv_local_rank", "--use-argv-local-rank", action="store_true",
                     help="also pass --local_rank=<i> on the child's command line (legacy torch.distributed.launch)")
-    ap.add_argument("--no_pin", "--no-pin", action="store_true", help="do not set HIP_VISIBLE_DEVICES per rank")
+    ap.add_argument("--no_pin", "--no-pin", action="store_true", help="do not export PDA_ASSIGNED_DEVICE per rank")
     ap.add_argument("--no_python", "--no-python", action="store_true")
     ap.add_argument("-m", "--module", action="store_true", help="run the script as a python module")
     ap.add_argument("--verbose", action="store_true")
