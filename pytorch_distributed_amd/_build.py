@@ -86,6 +86,30 @@ def build_kernels(force: bool = False, jobs: int | None = None, verbose: bool = 
     return KERNEL_LIB
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> Path:
+    """Experiment build: the kernel library compiled with extra ``-D`` flags into
+    ``lib/libpda_kernels_<name>.so`` (select it at run time with ``PDA_KERNELS_LIB=<path>``), so two
+    code-generation choices can be timed against each other inside one GPU session."""
+    srcs = sorted((CSRC / "kernels").glob("*.hip"))
+    out = LIB / f"libpda_kernels_{name}.so"
+    objdir = PKG / f"build_{name}"
+    objdir.mkdir(exist_ok=True)
+    LIB.mkdir(exist_ok=True)
+
+    def one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        if verbose:
+            print("[pda build]", name, src.name, flush=True)
+        _run([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+              "-I", str(CSRC / "kernels"), *[f"-D{d}" for d in defines], "-c", str(src), "-o", str(obj)])
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(one, srcs))
+    _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(out)] + [str(o) for o in objs])
+    return out
+
+
 def build_runtime(force: bool = False, verbose: bool = False) -> Path | None:
     srcs = sorted((CSRC / "runtime").glob("*.cc"))
     hdrs = sorted((CSRC / "runtime").glob("*.h"))
@@ -109,5 +133,9 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m pytorch_distributed_amd._build --variant NAME DEFINE[=V] ...
+        i = sys.argv.index("--variant")
+        print("built:", build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose=True)
     print("built:", KERNEL_LIB, RUNTIME_LIB if RUNTIME_LIB.exists() else "(no runtime sources yet)")

@@ -14,7 +14,8 @@ from pathlib import Path
 import torch
 
 _LIB = None
-_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libpda_kernels.so"
+_LIB_PATH = Path(os.environ.get("PDA_KERNELS_LIB") or
+                 Path(__file__).resolve().parent.parent / "lib" / "libpda_kernels.so")
 
 F32, F16, BF16, U8 = 0, 1, 2, 3
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.uint8: U8}
