@@ -59,17 +59,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(max(args.local_rank, 0))))
-    if not torch.cuda.is_available():
+    # PDA_BENCH_DEVICE=cpu: control-flow rehearsal of the multi-rank path (gloo, CPU reference ops) for the
+    # test-suite; numbers from it are not benchmark results and the JSON says so in "device".
+    on_cpu = os.environ.get("PDA_BENCH_DEVICE", "") == "cpu"
+    if not on_cpu and not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; bench.py needs an MI355X"}))
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_cpu:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     ddp = world > 1 or args.force_ddp
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if on_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pytorch_distributed_amd import models, ops, amp
     from pytorch_distributed_amd.optim import FusedSGD
@@ -91,7 +100,8 @@ def main():
                                     verbosity=0)
         if ddp:
             from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
-            model = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb, force_comm=args.force_ddp,
+            model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=args.bucket_mb,
+                        force_comm=args.force_ddp,
                         comm="native" if args.native_comm else None)
         metrics = ops.new_metrics(dev)
 
@@ -111,7 +121,7 @@ def main():
         opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
         scaler = torch.amp.GradScaler("cuda", enabled=(cdtype == torch.float16))
         if ddp:
-            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if on_cpu else [local_rank])
         crit = torch.nn.CrossEntropyLoss()
 
         def step():
@@ -126,7 +136,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not on_cpu:
+            torch.cuda.synchronize()
 
     graphed = False
     if args.graph and args.engine == "native" and not ddp:
@@ -162,6 +173,7 @@ def main():
                        "amp_opt_level": args.opt_level if args.precision != "fp32" else "O0",
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
+                       "device": "cpu (rehearsal, not a result)" if on_cpu else torch.cuda.get_device_name(dev),
                        "weights": "random-init", "final_loss": round(final_loss, 4), "hip_graph": graphed,
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }

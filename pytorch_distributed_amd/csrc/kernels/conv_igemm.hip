@@ -78,17 +78,19 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 #define PDA_IGEMM_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 template <typename T, int BM, int BN, int ROWB, int MODE>
-__global__ void __launch_bounds__(256) PDA_IGEMM_ATTR
+__global__ void __launch_bounds__(BM >= 256 ? 512 : 256) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
+  constexpr int WM = BM >= 256 ? 4 : 2;    // waves along M (x 2 along N); 256-row tiles run 8 waves
+  constexpr int NT = 128 * WM;             // threads per workgroup
   constexpr bool DGRAD = MODE != MODE_FPROP;
   constexpr bool PAR = MODE == MODE_DGRAD_S2;
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
   constexpr int BK = ROWB / sizeof(T);     // K elements per step
   constexpr int CPR = ROWB / 16;           // chunks per tile row
-  constexpr int RPT = 256 / CPR;           // tile rows covered by one pass of 256 threads
+  constexpr int RPT = NT / CPR;            // tile rows covered by one pass of the workgroup
   constexpr int A_IT = BM / RPT;           // chunks per thread, A tile
   constexpr int B_IT = BN / RPT;
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int WTM = BM / WM, WTN = BN / 2;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   static_assert(MI >= 1 && NI >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
 
@@ -379,8 +381,8 @@ igemm_kernel(ConvArgs a) {
     __syncthreads();
     constexpr int VPR = BN / EPC;  // vectors per tile row
 #pragma unroll
-    for (int k = 0; k < BM * VPR / 256; ++k) {
-      const int v = t + 256 * k;
+    for (int k = 0; k < BM * VPR / NT; ++k) {
+      const int v = t + NT * k;
       const int row = v / VPR, cv = v % VPR;
       const int m = m0e + row, n = n0 + cv * EPC;
       bool rok = m < a.M;
@@ -443,7 +445,7 @@ igemm_kernel(ConvArgs a) {
   }
 
   if (stats) {
-    float* sred = reinterpret_cast<float*>(lds);  // [2 wm][BN][2]; tiles are dead after the last barrier
+    float* sred = reinterpret_cast<float*>(lds);  // [WM][BN][2]; tiles are dead after the last barrier
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
@@ -456,8 +458,12 @@ igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
     if (t < BN && n0 + t < a.Co) {
-      const float v1 = sred[t * 2] + sred[(BN + t) * 2];
-      const float v2 = sred[t * 2 + 1] + sred[(BN + t) * 2 + 1];
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        v1 += sred[(w * BN + t) * 2];
+        v2 += sred[(w * BN + t) * 2 + 1];
+      }
       if (a.stat_slots > 0) {
         // few, pre-zeroed rows shared by many tiles: the finalize kernel that follows reads
         // stat_slots rows instead of one per tile (thousands for the early ResNet stages)
@@ -832,16 +838,18 @@ static int ilog2_exact(int v) {
 template <typename T, int BM, int BN, int ROWB>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
+  constexpr int NT = BM >= 256 ? 512 : 256;
   if (dgrad == MODE_DGRAD_S2)
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2>), dim3(4 * tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2>), dim3(4 * tiles), dim3(NT), 0, st, a);
   else if (dgrad == MODE_DGRAD)
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD>), dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD>), dim3(tiles), dim3(NT), 0, st, a);
   else
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP>), dim3(tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP>), dim3(tiles), dim3(NT), 0, st, a);
   return pda_check_launch();
 }
 
-// cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64; bit 3 forces 64-byte K rows.
+// cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves); bit 3 forces
+// 64-byte K rows.
 static int pick_tile(int M, int Co, int cfg) {
   int tile = cfg & 7;
   if (tile == 0) {
@@ -864,12 +872,16 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
     case 1: return use128 ? launch_igemm<T, 128, 128, 128>(a, dgrad, st) : launch_igemm<T, 128, 128, 64>(a, dgrad, st);
     case 2: return use128 ? launch_igemm<T, 128, 64, 128>(a, dgrad, st) : launch_igemm<T, 128, 64, 64>(a, dgrad, st);
     case 3: return use128 ? launch_igemm<T, 64, 64, 128>(a, dgrad, st) : launch_igemm<T, 64, 64, 64>(a, dgrad, st);
+    case 4: return use128 ? launch_igemm<T, 256, 128, 128>(a, dgrad, st) : launch_igemm<T, 256, 128, 64>(a, dgrad, st);
     default: return -2;
   }
 }
 
 // Block-tile rows used for a given cfg/shape (python sizes the stats partials with it).
-PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) { return pick_tile(M, Co, cfg) == 3 ? 64 : 128; }
+PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) {
+  const int tile = pick_tile(M, Co, cfg);
+  return tile == 3 ? 64 : tile == 4 ? 256 : 128;
+}
 
 // Returns 0 on success, <0 if the shape is not covered by the MFMA kernels
 // (caller falls back to the direct kernels), >0 = hipError_t.

@@ -70,7 +70,7 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
     assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], "wgrad"
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 10, 11, 12])
 def test_conv_tile_configs(cfg):
     torch.manual_seed(2)
     N, H, W, Cin, K = 3, 10, 10, 128, 192
