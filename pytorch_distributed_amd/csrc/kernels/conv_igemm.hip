@@ -26,6 +26,7 @@ struct ConvArgs {
   const void* w;    // [Co][R*S*Ci], K contiguous
   void* y;          // [M][Co]
   const void* res;  // optional [M][Co] added in the epilogue
+  const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res)
   float* psum;      // optional [tiles_m][Co] per-tile column sums of the output
   float* psq;       // optional [tiles_m][Co] per-tile column sums of squares
   long long sn, sh, sw;  // element strides of the gathered tensor
@@ -345,6 +346,7 @@ igemm_kernel(ConvArgs a) {
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (g&3)+8*(g>>2)+4*(lane>>5)
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   const T* __restrict__ Rz = reinterpret_cast<const T*>(a.res);
+  const T* __restrict__ Mk = reinterpret_cast<const T*>(a.mask);
   const bool stats = a.psum != nullptr;
   float csum[NI], csq[NI];
 #pragma unroll
@@ -406,6 +408,12 @@ igemm_kernel(ConvArgs a) {
           for (int e = 0; e < EPC; ++e)
             val.v[e] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(val.v[e]), 0.f));
         }
+        if (Mk != nullptr) {
+          const Vec16<T> mv = load16(Mk + o);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            if (!(ElemTraits<T>::to_f32(mv.v[e]) > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+        }
         store16(Y + o, val);
       }
     }
@@ -431,6 +439,7 @@ igemm_kernel(ConvArgs a) {
           const long long o = orow * a.Co + n;
           if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
           if (a.relu) v = fmaxf(v, 0.f);
+          if (Mk != nullptr && ok && !(ElemTraits<T>::to_f32(Mk[o]) > 0.f)) v = 0.f;
           const T tv = ElemTraits<T>::from_f32(v);
           if (ok) Y[o] = tv;
           if (stats) {
@@ -886,13 +895,13 @@ PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) {
 // Returns 0 on success, <0 if the shape is not covered by the MFMA kernels
 // (caller falls back to the direct kernels), >0 = hipError_t.
 PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
-                              float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                              const void* mask, float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
                               long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
                               int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
                               hipStream_t stream) {
   ConvArgs a;
   a.stat_slots = stat_slots;
-  a.x = x; a.w = w; a.y = y; a.res = res; a.psum = psum; a.psq = psq;
+  a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.psum = psum; a.psq = psq;
   a.sn = sn; a.sh = sh; a.sw = sw;
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co;
   a.R = R; a.S = S; a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;

@@ -29,7 +29,7 @@ c_ull = ctypes.c_ulonglong
 
 _SIGS = {
     "pda_conv_igemm_bm": [c_i, c_i, c_i],
-    "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
+    "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],

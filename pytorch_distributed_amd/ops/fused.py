@@ -25,7 +25,8 @@ from . import _lib, conv as C, norm as Nm, pool as P
 class _ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
-                cache: C.WeightCache, passthrough: bool = False):
+                cache: C.WeightCache, passthrough: bool = False, mask_dx: bool = False,
+                dout_premasked: bool = False):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -49,12 +50,16 @@ class _ConvBnActFn(torch.autograd.Function):
             y = r
             scale, shift = Nm.eval_coeffs(gamma, beta, st)
             mean = invstd = None
+            if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+                mean, invstd = Nm.eval_moments(st)   # frozen statistics, trainable affine
             count = float(y.numel() // K)
         out = Nm.apply(y, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
         ctx.beta = beta
-        mask_src = out if (relu and (residual is not None or not train_stats)) else None
-        ctx.save_for_backward(x, weight, y if train_stats else None, mask_src, mean, invstd, scale, shift, gamma)
+        ctx.mask_dx = mask_dx
+        ctx.premasked = bool(dout_premasked and relu)
+        mask_src = out if (relu and not ctx.premasked and (residual is not None or not train_stats)) else None
+        ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd, scale, shift, gamma)
         if passthrough:
             # second output = alias of the input: whatever consumes it (the block's identity branch)
             # sends its gradient back through THIS node, where the dgrad epilogue adds it for free
@@ -67,28 +72,38 @@ class _ConvBnActFn(torch.autograd.Function):
         stride, pad, relu, has_res, count, group, cache, train_stats = ctx.cfg
         dout = dout.contiguous()
         K, Cin, R, S = weight.shape
-        if train_stats:
+        if train_stats and ctx.premasked:
+            # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
+            # residual branch's gradient IS dout
+            dy, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False,
+                                        False, group, ctx.beta, cache.stats_buffer(K, dout.device))
+            dres = dout if has_res else None
+        elif train_stats:
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
                                            has_res, group, ctx.beta, cache.stats_buffer(K, dout.device))
         else:
-            g = dout if not relu else dout * (mask_src > 0).to(dout.dtype)
+            g = dout if (not relu or ctx.premasked) else dout * (mask_src > 0).to(dout.dtype)
             dy = (g.float() * scale).to(dout.dtype)
             dres = g if has_res else None
             dg = db = None
+            if mean is not None:
+                dg, db = Nm.eval_affine_grads(g, y, mean, invstd)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if dalias is not None:
                 dalias = dalias.contiguous()
             dx = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
-                             res=dalias)
+                             res=dalias, mask=x if ctx.mask_dx else None)
             if dx is None:
                 dx = torch.empty_like(x)
                 C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
                               (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
                 if dalias is not None:
                     dx = dx + dalias
+                if ctx.mask_dx:
+                    dx = dx * (x > 0).to(dx.dtype)
         elif dalias is not None:
-            dx = dalias
+            dx = dalias * (x > 0).to(dalias.dtype) if ctx.mask_dx else dalias
         if ctx.needs_input_grad[1]:
             sink = C.grad_sink(weight)
             dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink)
@@ -102,22 +117,51 @@ class _ConvBnActFn(torch.autograd.Function):
                     dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-        return dx, dw, dg, db, dres, None, None, None, None, None, None
+        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
-                cache: Optional[C.WeightCache] = None, passthrough: bool = False):
+                cache: Optional[C.WeightCache] = None, passthrough: bool = False, mask_dx: bool = False,
+                dout_premasked: bool = False):
     """NHWC fused conv + BatchNorm (+residual) (+ReLU).
 
     ``passthrough=True`` returns ``(out, x_alias)``: feed ``x_alias`` to the other consumer of ``x``
     (the residual branch of a ResNet block) and its gradient is summed inside this op's dgrad
-    epilogue instead of by a separate element-wise add."""
+    epilogue instead of by a separate element-wise add.
+
+    ``mask_dx`` / ``dout_premasked`` move a ReLU backward from the op that owns the ReLU into the op that
+    consumes its output.  A consumer called with ``mask_dx=True`` declares that ``x`` is a ReLU output
+    whose every use goes through this op (``passthrough`` covers the skip branch) and writes its input
+    gradient already multiplied by ``x > 0``; the producer, called with ``dout_premasked=True``, then
+    skips its own mask: it neither re-reads its output nor writes a separate masked copy for its
+    residual branch.  ``dout_premasked`` without a masking consumer gives wrong gradients; ``mask_dx``
+    alone is always correct (masking twice is harmless)."""
     if not x.is_cuda:
+        # reference path: the ReLU masks its own gradient, so both hints can be ignored together
         y = C.conv2d_ref(x, weight, None, stride, pad)
         o = Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
         return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
-                              cache or C.WeightCache(), passthrough)
+                              cache or C.WeightCache(), passthrough, mask_dx, dout_premasked)
+
+
+class _GradMaskFn(torch.autograd.Function):
+    """Identity whose gradient is zeroed where ``x <= 0`` (the ``mask_dx`` contract for code paths that
+    do not run the fused op)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * (x > 0).to(g.dtype)
+
+
+def grad_mask(x: torch.Tensor) -> torch.Tensor:
+    return _GradMaskFn.apply(x)
 
 
 # ------------------------------------------------------------------------------------ stem
@@ -180,6 +224,8 @@ class _StemFn(torch.autograd.Function):
             y = r
             scale, shift = Nm.eval_coeffs(gamma, beta, st)
             mean_ = invstd = None
+            if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+                mean_, invstd = Nm.eval_moments(st)
             count = float(y.numel() // K)
         act = Nm.apply(y, scale, shift, None, True)
         if pool is not None:
@@ -188,7 +234,7 @@ class _StemFn(torch.autograd.Function):
             out, idx = act, None
         ctx.cfg = (stride, pad, geom, count, st.group, pool, act.shape, train_stats, weight.shape)
         ctx.beta = beta
-        ctx.save_for_backward(xp, y if train_stats else None, idx, mean_, invstd, scale, shift, gamma,
+        ctx.save_for_backward(xp, y if (train_stats or mean_ is not None) else None, idx, mean_, invstd, scale, shift, gamma,
                               act if not train_stats else None)
         return out
 
@@ -203,8 +249,11 @@ class _StemFn(torch.autograd.Function):
             dy, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group,
                                         ctx.beta)
         else:
-            dy = ((dact * (act > 0).to(dact.dtype)).float() * scale).to(dact.dtype)
+            g = dact * (act > 0).to(dact.dtype)
+            dy = (g.float() * scale).to(dact.dtype)
             dg = db = None
+            if mean_ is not None:
+                dg, db = Nm.eval_affine_grads(g, y, mean_, invstd)
         dw = None
         if ctx.needs_input_grad[1]:
             dwk = C.wgrad_gpu(dy, xp, R, 1, (stride[0], 1), (0, 0), geom=geom)  # [K][R][1][32]

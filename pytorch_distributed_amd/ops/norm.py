@@ -101,6 +101,19 @@ def eval_coeffs(gamma, beta, st: BNState):
     return out[0], out[1]
 
 
+def eval_moments(st: BNState):
+    """(mean, invstd) of eval-mode normalisation: the running statistics, as fp32 vectors."""
+    return st.running_mean.float(), torch.rsqrt(st.running_var.float() + st.eps)
+
+
+def eval_affine_grads(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor):
+    """dgamma, dbeta of eval-mode BatchNorm (fixed statistics: dgamma = sum g*xhat, dbeta = sum g).
+    Fine-tuning with frozen statistics is rare enough that plain tensor ops do."""
+    dims = tuple(range(g.dim() - 1))
+    gf = g.float()
+    return (gf * ((y.float() - mean) * invstd)).sum(dims), gf.sum(dims)
+
+
 def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
     l = _lib.lib()
     C = y.shape[-1]
@@ -196,17 +209,22 @@ class _BatchNormActFn(torch.autograd.Function):
         ctx.beta = beta
         if ctx.train:
             ctx.save_for_backward(y, out if (relu and residual is not None) else None, mean, invstd, scale, shift, gamma)
+        elif gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            ctx.save_for_backward(out if relu else None, scale, y, *eval_moments(st))
         else:
-            ctx.save_for_backward(out if relu else None, scale)
+            ctx.save_for_backward(out if relu else None, scale, None, None, None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous()
         if not ctx.train:  # eval-mode BN is an affine map
-            out, scale = ctx.saved_tensors
+            out, scale, y, mean, invstd = ctx.saved_tensors
             g = dout if out is None else dout * (out > 0).to(dout.dtype)
-            return (g.float() * scale).to(dout.dtype), None, None, (g if ctx.has_res else None), None, None
+            dg = db = None
+            if y is not None:
+                dg, db = eval_affine_grads(g, y, mean, invstd)
+            return (g.float() * scale).to(dout.dtype), dg, db, (g if ctx.has_res else None), None, None
         y, out, mean, invstd, scale, shift, gamma = ctx.saved_tensors
         dy, dres, dg, db = backward(dout, y, out, mean, invstd, scale, shift, gamma, ctx.count, ctx.relu,
                                     ctx.has_res, ctx.group, ctx.beta)

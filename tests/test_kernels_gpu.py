@@ -236,6 +236,40 @@ def test_batchnorm_eval():
     assert rel_err(out, ref) < 2e-2
 
 
+def test_eval_mode_backward_gives_affine_grads():
+    """Frozen statistics, trainable affine: eval-mode backward of the stand-alone and the conv-fused op
+    returns d(input), d(gamma), d(beta) like torch's eval-mode batch_norm."""
+    torch.manual_seed(61)
+    conv = pnn.Conv2d(64, 128, 3, 1, 1, bias=False).to(DEV)
+    bn = pnn.BatchNorm2d(128).to(DEV)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    bn.eval()
+    rconv = torch.nn.Conv2d(64, 128, 3, 1, 1, bias=False).to(DEV)
+    rbn = torch.nn.BatchNorm2d(128).to(DEV).eval()
+    rconv.load_state_dict(conv.state_dict())
+    rbn.load_state_dict(bn.state_dict())
+    x = torch.randn(2, 9, 9, 64, device=DEV, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    g = torch.randn(2, 9, 9, 128, device=DEV)
+    for fused in (True, False):
+        for m in (conv, bn, rconv, rbn):
+            m.zero_grad(set_to_none=True)
+        x.grad = xr.grad = None
+        out = pnn.ConvBnAct.run(conv, bn, x, relu=True) if fused else bn(conv(x), None, True)
+        ref = torch.relu(rbn(rconv(xr.permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+        assert rel_err(out, ref) < 1e-3
+        out.backward(g)
+        ref.backward(g)
+        assert rel_err(x.grad, xr.grad) < 2e-3
+        assert rel_err(bn.weight.grad, rbn.weight.grad) < 2e-3, fused
+        assert rel_err(bn.bias.grad, rbn.bias.grad) < 2e-3, fused
+        assert rel_err(conv.weight.grad, rconv.weight.grad) < 2e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("shape,k,s,p", [((2, 16, 16, 64), 3, 2, 1), ((3, 24, 24, 10), 2, 2, 0), ((2, 9, 9, 20), 2, 2, 0)])
 def test_maxpool(shape, k, s, p, dtype):
@@ -461,6 +495,59 @@ def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw, batch):
         alla = torch.cat([gr[k].grad.float().flatten() for k in g])
         stock_total = _cos(alla, allr)
         assert total > stock_total - 0.05, (total, stock_total, median, cos[:3])
+
+
+@pytest.mark.parametrize("arch,dtype,hw,batch", [("resnet18", torch.float32, 32, 8), ("resnet50", torch.float16, 64, 16),
+                                                 ("resnet50", torch.bfloat16, 64, 16)])
+def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch):
+    """Block-output ReLU masks applied in the next block's dgrad epilogue == applied by the owning BatchNorm
+    backward: the same gradients, train and eval mode."""
+    torch.manual_seed(21)
+    m = models.get_model(arch).to(DEV).set_compute_dtype(dtype)
+    x = torch.randn(batch, 3, hw, hw, device=DEV)
+    t = torch.randint(0, 1000, (batch,), device=DEV)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for mode in (True, False):
+        grads = []
+        for fuse in (True, False):
+            m.fuse_relu_backward(fuse)
+            assert m.layer1[0].premasked_out == fuse and m.layer1[1].premask_in == fuse
+            assert not m.layer1[0].premask_in and not m.layer4[-1].premasked_out
+            m.load_state_dict(sd)  # train mode moves the running statistics: every run starts from the same state
+            m.train(mode)
+            m.zero_grad(set_to_none=True)
+            (ops.cross_entropy(m(x), t) * 256.0).backward()
+            missing = [k for k, p in m.named_parameters() if p.grad is None]
+            assert not missing, (mode, fuse, missing)
+            grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        for k in grads[0]:
+            # identical arithmetic; only the float-atomic split-K sums of some wgrad launches are
+            # order-dependent from run to run (1e-6-level), a wrong mask would be an O(1) difference
+            assert rel_err(grads[0][k], grads[1][k]) < 1e-4, (mode, k)
+    m.fuse_relu_backward(True)
+    # a forward hook on a block may leak its output to an unknown consumer: that block keeps its own mask
+    h = m.layer2[1].register_forward_hook(lambda mod, i, o: None)
+    from pytorch_distributed_amd.models.resnet import _premasked_out
+    assert not _premasked_out(m.layer2[1]) and _premasked_out(m.layer2[0])
+    h.remove()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_dgrad_mask_epilogue(dtype, stride):
+    torch.manual_seed(22)
+    N, H, W, Cin, K = 3, 12, 12, 64, 128
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 24).to(dtype).permute(0, 3, 1, 2)
+    Ho = (H + 2 - 3) // stride + 1
+    dy = torch.randn(N, Ho, Ho, K, device=DEV).to(dtype)
+    res = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    xm = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    plain = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=res)
+    masked = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=res, mask=xm)
+    assert torch.equal(masked, plain * (xm > 0).to(dtype))
+    with pytest.raises(ValueError):
+        C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), mask=xm[:, :-1])
 
 
 def test_mnist_net_gpu_matches_cpu():
