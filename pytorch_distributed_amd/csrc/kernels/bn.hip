@@ -408,12 +408,14 @@ bn_bwd_finalize_kernel(float* __restrict__ pdg, float* __restrict__ pdb, int npa
                        const float* __restrict__ invstd, const float* __restrict__ scale,
                        const float* __restrict__ shift, const float* __restrict__ gamma, float inv_count,
                        float* __restrict__ coef, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta,
-                       int clear) {
+                       int clear, int raw) {
   __shared__ typename PartialReduce<CH>::Scratch red;
   int c, pl;
   double a, b;
   PartialReduce<CH>::run(pdg, pdb, nparts, C, c, pl, a, b, red, clear);
   if (pl != 0 || c >= C) return;
+  // raw partials (written by a dgrad epilogue): pdb = sum(g), pdg = sum(g*y) -> sum(g*xhat)
+  if (raw) a = (double)invstd[c] * (a - (double)mean[c] * b);
   dgamma[c] = (float)a;
   dbeta[c] = (float)b;
   // parameter gradients accumulated straight into the optimizer's / reducer's buffers
@@ -556,15 +558,15 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
 PDA_EXPORT int pda_bn_bwd_finalize(float* pdg, float* pdb, int nparts, int C, float* dgamma,
                                    float* dbeta, const float* mean, const float* invstd, const float* scale,
                                    const float* shift, const float* gamma, double count, float* coef,
-                                   float* acc_dgamma, float* acc_dbeta, int clear, hipStream_t st) {
+                                   float* acc_dgamma, float* acc_dbeta, int clear, int raw, hipStream_t st) {
   if (partial_ch(nparts, C) == 4)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, pdg, pdb, nparts, C, dgamma,
                        dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma, acc_dbeta,
-                       clear);
+                       clear, raw);
   else
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, pdg, pdb, nparts, C,
                        dgamma, dbeta, mean, invstd, scale, shift, gamma, (float)(1.0 / count), coef, acc_dgamma,
-                       acc_dbeta, clear);
+                       acc_dbeta, clear, raw);
   return pda_check_launch();
 }
 

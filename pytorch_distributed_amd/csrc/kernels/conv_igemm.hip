@@ -27,6 +27,13 @@ struct ConvArgs {
   void* y;          // [M][Co]
   const void* res;  // optional [M][Co] added in the epilogue
   const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res)
+  // BatchNorm backward of the layer that produced this conv's input, folded into a dgrad epilogue:
+  // bnc = that layer's pre-normalisation tensor [M][Co].  With bn_scale/bn_shift the layer's ReLU mask
+  // (bnc*scale+shift > 0) is applied to the output; with psum/psq the per-tile column sums of the final
+  // output v and of v*bnc are written there (instead of the fprop statistics sum(y), sum(y^2)).
+  const void* bnc;
+  const float* bn_scale;
+  const float* bn_shift;
   float* psum;      // optional [tiles_m][Co] per-tile column sums of the output
   float* psq;       // optional [tiles_m][Co] per-tile column sums of squares
   long long sn, sh, sw;  // element strides of the gathered tensor
@@ -78,7 +85,9 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 #ifndef PDA_IGEMM_ATTR
 #define PDA_IGEMM_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
-template <typename T, int BM, int BN, int ROWB, int MODE>
+// EX: the epilogue extras (res, mask, bnc) are compiled in; the plain instantiation keeps the lean
+// write-out (the extras cost registers and scalar state even when their pointers are null).
+template <typename T, int BM, int BN, int ROWB, int MODE, bool EX>
 __global__ void __launch_bounds__(BM >= 256 ? 512 : 256) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
   constexpr int WM = BM >= 256 ? 4 : 2;    // waves along M (x 2 along N); 256-row tiles run 8 waves
@@ -110,7 +119,7 @@ igemm_kernel(ConvArgs a) {
   const int tiles_n = (a.Co + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int ph = 0, pw = 0;
+  int ph = 0, pw = 0, pcls = 0;
   if (PAR) {
     // the four classes of one tile position run as neighbouring workgroups (same XCD after the
     // remap): they gather the same dY region and together write whole runs of output pixels
@@ -121,6 +130,7 @@ igemm_kernel(ConvArgs a) {
     const int cls = (bid + grp) & 3;
     ph = cls >> 1;
     pw = cls & 1;
+    pcls = cls;
     bid = grp;
   }
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
@@ -345,9 +355,13 @@ igemm_kernel(ConvArgs a) {
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (g&3)+8*(g>>2)+4*(lane>>5)
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
-  const T* __restrict__ Rz = reinterpret_cast<const T*>(a.res);
-  const T* __restrict__ Mk = reinterpret_cast<const T*>(a.mask);
+  const T* __restrict__ Rz = EX ? reinterpret_cast<const T*>(a.res) : nullptr;
+  const T* __restrict__ Mk = EX ? reinterpret_cast<const T*>(a.mask) : nullptr;
+  const T* __restrict__ Bc = EX ? reinterpret_cast<const T*>(a.bnc) : nullptr;
   const bool stats = a.psum != nullptr;
+  const bool gstats = stats && Bc != nullptr;  // sums of the final values and of value*bnc
+  const bool remask = Bc != nullptr && a.bn_scale != nullptr;
+  const int prow = PAR ? pcls * tiles_m + tm : tm;  // row of the per-tile statistics
   float csum[NI], csq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
@@ -362,28 +376,17 @@ igemm_kernel(ConvArgs a) {
   const bool vec_epi = (sizeof(T) == 2) && (a.Co % EPC == 0);
   if (vec_epi) {
     constexpr int CP = BN * (int)sizeof(T) + 16;  // padded row pitch, keeps 16-byte alignment
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int col = wn * WTN + j * 32 + l31;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-          const T tv = ElemTraits<T>::from_f32(acc[i][j][g]);
-          *reinterpret_cast<T*>(lds + row * CP + col * (int)sizeof(T)) = tv;
-          if (stats) {
-            // rows past M come from all-zero A rows, so they add nothing
-            const float fv = ElemTraits<T>::to_f32(tv);
-            csum[j] += fv;
-            csq[j] += fv * fv;
-          }
-        }
-      }
-    __syncthreads();
-    constexpr int VPR = BN / EPC;  // vectors per tile row
-#pragma unroll
-    for (int k = 0; k < BM * VPR / NT; ++k) {
+    constexpr int VPR = BN / EPC;                 // 16-byte vectors per tile row
+    constexpr int KI = BM * VPR / NT;             // vectors written by one thread
+    static_assert(NT % VPR == 0, "a thread keeps one vector column for all of its rows");
+    // Everything the write-out reads from global memory (residual, mask, BatchNorm operand) is requested
+    // here, before the accumulators are staged through LDS: all KI vectors of a stream in one batch with
+    // no branch between them (a thread without a valid k-th vector reads element 0 instead), so their
+    // latencies overlap each other and the staging pass instead of adding up per row.
+    constexpr int KE = EX ? KI : 1;
+    long long eo[KE];
+    bool eok[KE];
+    auto vec_offset = [&](int k, long long& o) -> bool {
       const int v = t + NT * k;
       const int row = v / VPR, cv = v % VPR;
       const int m = m0e + row, n = n0 + cv * EPC;
@@ -394,14 +397,75 @@ igemm_kernel(ConvArgs a) {
         rok = decode(m, pn, pho, pwo);
         orow = ((long long)pn * a.Ho + pho) * a.Wo + pwo;
       }
-      if (rok && n < a.Co) {
+      const bool ok = rok && n < a.Co;
+      o = ok ? orow * a.Co + n : 0;
+      return ok;
+    };
+    if constexpr (EX) {
+#pragma unroll
+      for (int k = 0; k < KI; ++k) eok[k] = vec_offset(k, eo[k]);
+    }
+    Vec16<T> rv[KE], mv[KE], bv[KE];
+    if (Rz != nullptr) {
+#pragma unroll
+      for (int k = 0; k < KE; ++k) rv[k] = load16(Rz + eo[k]);
+    }
+    if (Mk != nullptr) {
+#pragma unroll
+      for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + eo[k]);
+    }
+    if (Bc != nullptr) {
+#pragma unroll
+      for (int k = 0; k < KE; ++k) bv[k] = load16(Bc + eo[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          const T tv = ElemTraits<T>::from_f32(acc[i][j][g]);
+          *reinterpret_cast<T*>(lds + row * CP + col * (int)sizeof(T)) = tv;
+          if (stats && !gstats) {
+            // rows past M come from all-zero A rows, so they add nothing
+            const float fv = ElemTraits<T>::to_f32(tv);
+            csum[j] += fv;
+            csq[j] += fv * fv;
+          }
+        }
+      }
+    __syncthreads();
+    const int cvt = t % VPR;
+    float g1[EPC], g2[EPC], msc[EPC], msf[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { g1[e] = 0.f; g2[e] = 0.f; msc[e] = 0.f; msf[e] = 0.f; }
+    if (remask && n0 + cvt * EPC < a.Co) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        msc[e] = a.bn_scale[n0 + cvt * EPC + e];
+        msf[e] = a.bn_shift[n0 + cvt * EPC + e];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int v = t + NT * k;
+      const int row = v / VPR, cv = v % VPR;
+      long long o;
+      bool ok;
+      if constexpr (EX) {
+        o = eo[k];
+        ok = eok[k];
+      } else {
+        ok = vec_offset(k, o);
+      }
+      if (ok) {
         Vec16<T> val = *reinterpret_cast<const Vec16<T>*>(lds + row * CP + cv * 16);
-        const long long o = orow * a.Co + n;
         if (Rz != nullptr) {
-          const Vec16<T> rv = load16(Rz + o);
 #pragma unroll
           for (int e = 0; e < EPC; ++e)
-            val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + ElemTraits<T>::to_f32(rv.v[e]));
+            val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + ElemTraits<T>::to_f32(rv[EX ? k : 0].v[e]));
         }
         if (a.relu) {
 #pragma unroll
@@ -409,15 +473,45 @@ igemm_kernel(ConvArgs a) {
             val.v[e] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(val.v[e]), 0.f));
         }
         if (Mk != nullptr) {
-          const Vec16<T> mv = load16(Mk + o);
 #pragma unroll
           for (int e = 0; e < EPC; ++e)
-            if (!(ElemTraits<T>::to_f32(mv.v[e]) > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+            if (!(ElemTraits<T>::to_f32(mv[EX ? k : 0].v[e]) > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+        }
+        if (Bc != nullptr) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float cf = ElemTraits<T>::to_f32(bv[EX ? k : 0].v[e]);
+            if (remask && !(cf * msc[e] + msf[e] > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+            const float vf = ElemTraits<T>::to_f32(val.v[e]);
+            g1[e] += vf;
+            g2[e] += vf * cf;
+          }
         }
         store16(Y + o, val);
       }
     }
     if (stats) __syncthreads();  // the statistics scratch below reuses the staging area
+    if (gstats) {
+      // threads t, t+VPR, t+2*VPR, ... hold the same 8 columns: fold them through LDS
+      float* gred = reinterpret_cast<float*>(lds);  // [NT/VPR][BN][2]
+      const int grp = t / VPR;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        gred[((grp * BN) + cvt * EPC + e) * 2 + 0] = g1[e];
+        gred[((grp * BN) + cvt * EPC + e) * 2 + 1] = g2[e];
+      }
+      __syncthreads();
+      if (t < BN && n0 + t < a.Co) {
+        float v1 = 0.f, v2 = 0.f;
+        for (int w = 0; w < NT / VPR; ++w) {
+          v1 += gred[(w * BN + t) * 2];
+          v2 += gred[(w * BN + t) * 2 + 1];
+        }
+        a.psum[(long long)prow * a.Co + n0 + t] = v1;
+        a.psq[(long long)prow * a.Co + n0 + t] = v2;
+      }
+      return;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -440,6 +534,11 @@ igemm_kernel(ConvArgs a) {
           if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
           if (a.relu) v = fmaxf(v, 0.f);
           if (Mk != nullptr && ok && !(ElemTraits<T>::to_f32(Mk[o]) > 0.f)) v = 0.f;
+          float cf = 0.f;
+          if (Bc != nullptr && ok) {
+            cf = ElemTraits<T>::to_f32(Bc[o]);
+            if (remask && !(cf * a.bn_scale[n] + a.bn_shift[n] > 0.f)) v = 0.f;
+          }
           const T tv = ElemTraits<T>::from_f32(v);
           if (ok) Y[o] = tv;
           if (stats) {
@@ -447,7 +546,7 @@ igemm_kernel(ConvArgs a) {
             // that the normalisation pass will read back
             const float fv = ok ? ElemTraits<T>::to_f32(tv) : 0.f;
             csum[j] += fv;
-            csq[j] += fv * fv;
+            csq[j] += gstats ? fv * cf : fv * fv;
           }
         }
       }
@@ -476,12 +575,12 @@ igemm_kernel(ConvArgs a) {
       if (a.stat_slots > 0) {
         // few, pre-zeroed rows shared by many tiles: the finalize kernel that follows reads
         // stat_slots rows instead of one per tile (thousands for the early ResNet stages)
-        const long long o = (long long)(tm % a.stat_slots) * a.Co + n0 + t;
+        const long long o = (long long)(prow % a.stat_slots) * a.Co + n0 + t;
         atomicAdd(a.psum + o, v1);
         atomicAdd(a.psq + o, v2);
       } else {
-        a.psum[(long long)tm * a.Co + n0 + t] = v1;
-        a.psq[(long long)tm * a.Co + n0 + t] = v2;
+        a.psum[(long long)prow * a.Co + n0 + t] = v1;
+        a.psq[(long long)prow * a.Co + n0 + t] = v2;
       }
     }
   }
@@ -848,12 +947,17 @@ template <typename T, int BM, int BN, int ROWB>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
   constexpr int NT = BM >= 256 ? 512 : 256;
-  if (dgrad == MODE_DGRAD_S2)
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2>), dim3(4 * tiles), dim3(NT), 0, st, a);
-  else if (dgrad == MODE_DGRAD)
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD>), dim3(tiles), dim3(NT), 0, st, a);
-  else
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP>), dim3(tiles), dim3(NT), 0, st, a);
+  const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
+  if (dgrad == MODE_DGRAD_S2) {
+    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, true>), dim3(4 * tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, false>), dim3(4 * tiles), dim3(NT), 0, st, a);
+  } else if (dgrad == MODE_DGRAD) {
+    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD, true>), dim3(tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD, false>), dim3(tiles), dim3(NT), 0, st, a);
+  } else {
+    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, true>), dim3(tiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false>), dim3(tiles), dim3(NT), 0, st, a);
+  }
   return pda_check_launch();
 }
 
@@ -892,16 +996,27 @@ PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) {
   return tile == 3 ? 64 : tile == 4 ? 256 : 128;
 }
 
+// Rows of per-tile sums a dgrad launch with bnc/psum writes: N x Hx x Wx x Cx is the dX tensor.
+PDA_EXPORT int pda_conv_dgrad_stat_rows(int N, int Hx, int Wx, int Cx, int stride_h, int stride_w, int cfg) {
+  const bool par = stride_h == 2 && stride_w == 2 && (cfg & 16) == 0;
+  const long long M = par ? (long long)N * ((Hx + 1) / 2) * ((Wx + 1) / 2) : (long long)N * Hx * Wx;
+  const int tile = pick_tile((int)M, Cx, cfg);
+  const int bm = tile == 3 ? 64 : tile == 4 ? 256 : 128;
+  return (int)((M + bm - 1) / bm) * (par ? 4 : 1);
+}
+
 // Returns 0 on success, <0 if the shape is not covered by the MFMA kernels
 // (caller falls back to the direct kernels), >0 = hipError_t.
 PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
-                              const void* mask, float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                              const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
+                              float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
                               long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
                               int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
                               hipStream_t stream) {
   ConvArgs a;
   a.stat_slots = stat_slots;
-  a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.psum = psum; a.psq = psq;
+  a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.bnc = bnc; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+  a.psum = psum; a.psq = psq;
   a.sn = sn; a.sh = sh; a.sw = sw;
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co;
   a.R = R; a.S = S; a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
@@ -909,6 +1024,7 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
   a.M = N * Ho * Wo; a.relu = relu;
   a.Ha = a.Wb = 0;
   if (a.M <= 0 || Co <= 0) return 0;
+  if (bnc != nullptr && (!dgrad || stat_slots > 0)) return -7;
   if (dgrad && (a.sh_log2 < 0 || a.sw_log2 < 0)) return -3;
   if ((long long)N * Ho * Wo > 0x7fffffffLL) return -4;
   {

@@ -22,6 +22,7 @@ import torch.nn as tnn
 
 from .. import nn as pnn
 from .. import ops
+from ..ops.fused import BNBackwardLink
 
 
 def _conv3x3(cin, cout, stride=1):
@@ -38,6 +39,24 @@ def _premasked_out(block) -> bool:
     return block.premasked_out and not block._forward_hooks
 
 
+def _init_fusion_state(block) -> None:
+    block.premask_in = False     # see ResNet.fuse_relu_backward
+    block.premasked_out = False
+    block.fuse_inner = True      # backward hand-off between the convs inside the block
+    block._link_in = None        # per-forward: set by ResNet.features for the first conv
+    block._link_out = None       # per-forward: read (and cleared) by ResNet.features
+
+
+def _links(block, n_inner: int):
+    """Per-forward backward links of a block: (link from the previous block, inner links, link to the
+    next block, whether the block's output gradient arrives masked)."""
+    in_link, block._link_in = (block._link_in if block.premask_in else None), None
+    inner = tuple(BNBackwardLink() if block.fuse_inner else None for _ in range(n_inner))
+    pm = _premasked_out(block)
+    block._link_out = BNBackwardLink() if pm else None
+    return in_link, inner, block._link_out, pm
+
+
 class BasicBlock(tnn.Module):
     expansion = 1
 
@@ -50,18 +69,19 @@ class BasicBlock(tnn.Module):
         self.bn2 = pnn.BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
-        self.premask_in = False    # see ResNet.fuse_relu_backward
-        self.premasked_out = False
+        _init_fusion_state(self)
 
     def forward(self, x):
         # `identity` is an alias of x handed back by conv1's op, so the gradient of the skip branch
         # is added inside conv1's dgrad epilogue rather than by a separate kernel
+        in_link, l1, lo, pm = _links(self, 1)
         out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True,
-                                          mask_dx=self.premask_in)
+                                          mask_dx=self.premask_in, in_link=in_link,
+                                          dout_premasked=l1[0] is not None, out_link=l1[0])
         if self.downsample is not None:
             identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
-        return pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, residual=identity,
-                                 dout_premasked=_premasked_out(self))
+        return pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, residual=identity, in_link=l1[0],
+                                 dout_premasked=pm, out_link=lo)
 
 
 class Bottleneck(tnn.Module):
@@ -78,17 +98,19 @@ class Bottleneck(tnn.Module):
         self.relu = pnn.ReLU()
         self.downsample = downsample
         self.stride = stride
-        self.premask_in = False    # see ResNet.fuse_relu_backward
-        self.premasked_out = False
+        _init_fusion_state(self)
 
     def forward(self, x):
+        in_link, (l1, l2), lo, pm = _links(self, 2)
         out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True,
-                                          mask_dx=self.premask_in)
-        out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True)
+                                          mask_dx=self.premask_in, in_link=in_link,
+                                          dout_premasked=l1 is not None, out_link=l1)
+        out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, in_link=l1,
+                                dout_premasked=l2 is not None, out_link=l2)
         if self.downsample is not None:
             identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
-        return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity,
-                                 dout_premasked=_premasked_out(self))
+        return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity, in_link=l2,
+                                 dout_premasked=pm, out_link=lo)
 
 
 class ResNet(tnn.Module):
@@ -139,11 +161,15 @@ class ResNet(tnn.Module):
         that epilogue also applies the ``output > 0`` mask, and the block that owns the ReLU skips it: its
         BatchNorm backward stops re-reading the block output and stops writing a separate masked copy of
         the gradient for the skip branch (about 4 bytes per activation element less HBM traffic).  The
-        arithmetic is the same either way.  Turn it off (``model.fuse_relu_backward(False)``) when code
+        same switch covers the hand-off between consecutive convs (inside a block and across blocks): the
+        dgrad epilogue that writes a gradient tile also takes the two per-channel sums that the BatchNorm
+        backward of the producing layer needs, which removes that layer's separate reduction pass over
+        the gradient and the activation.  The arithmetic is the same either way.  Turn it off (``model.fuse_relu_backward(False)``) when code
         outside the model consumes a block's output directly, e.g. a feature tap between two blocks."""
         blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
         for b in blocks:
             b.premask_in = b.premasked_out = False
+            b.fuse_inner = bool(enable)
         if enable:
             for prev, nxt in zip(blocks[:-1], blocks[1:]):
                 prev.premasked_out = True
@@ -172,10 +198,15 @@ class ResNet(tnn.Module):
                                        self.conv1.padding, self.bn1.state(), self.compute_dtype,
                                        pool=(self.maxpool.kernel_size, self.maxpool.stride, self.maxpool.padding),
                                        mean=self._in_mean, inv_std=self._in_inv_std, pre_scale=self.input_scale)
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        x = self.layer4(x)
+        # block by block (what nn.Sequential would do) so that each block's backward link reaches the
+        # block that consumes its output; the link is dropped from the modules right away - only the
+        # autograd nodes of this forward keep it
+        link = None
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in layer:
+                block._link_in = link
+                x = block(x)
+                link, block._link_out = block._link_out, None
         return x
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:

@@ -111,18 +111,22 @@ class ConvBnAct(tnn.Module):
     @staticmethod
     def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
             residual: Optional[torch.Tensor] = None, passthrough: bool = False, mask_dx: bool = False,
-            dout_premasked: bool = False):
-        """``mask_dx`` / ``dout_premasked``: see :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
+            dout_premasked: bool = False, in_link=None, out_link=None):
+        """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
+        :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
         if conv.bias is not None:
-            # unfused modules: the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing),
-            # and the promise made by mask_dx is kept by an explicit gradient mask on x
-            if mask_dx and x.is_cuda:
+            # unfused modules: the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
+            # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
+            # gradient mask on x
+            if (mask_dx or (in_link is not None and in_link.relu)) and x.is_cuda:
                 from ..ops.fused import grad_mask
                 x = grad_mask(x)
+            if out_link is not None:
+                out_link.relu = relu
             o = bn(conv(x), residual, relu)
             return (o, x) if passthrough else o
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
-                               bn.state(), conv._cache, passthrough, mask_dx, dout_premasked)
+                               bn.state(), conv._cache, passthrough, mask_dx, dout_premasked, in_link, out_link)
 
 
 class ReLU(tnn.Module):

@@ -29,7 +29,8 @@ c_ull = ctypes.c_ulonglong
 
 _SIGS = {
     "pda_conv_igemm_bm": [c_i, c_i, c_i],
-    "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
+    "pda_conv_dgrad_stat_rows": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
+    "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
@@ -44,7 +45,7 @@ _SIGS = {
     "pda_bn_eval_coeffs": [c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "pda_bn_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_bn_bwd_reduce": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_i, c_p],
-    "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_i, c_p],
+    "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_i, c_i, c_p],
     "pda_bn_bwd_coefs": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p],
     "pda_bn_bwd_apply": [c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
     "pda_maxpool_fwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

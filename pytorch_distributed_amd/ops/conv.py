@@ -87,7 +87,7 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
         else:
             part = torch.empty((2, tiles_m, K), device=x.device, dtype=torch.float32)
             psum, psq = part[0], part[1]
-    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0,
+    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0, 0, 0, 0,
                           _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
                           stride[0], stride[1], pad[0], pad[1], int(relu), cfg, slots, _lib.stream())
     if rc < 0:
@@ -97,27 +97,43 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
 
 
 def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], stride, pad,
-              res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None):
+              res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None,
+              bn_input: Optional[torch.Tensor] = None, bn_scale: Optional[torch.Tensor] = None,
+              bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False):
     """dx[N,Hi,Wi,C] from dy[N,Ho,Wo,K]; w_crsk is the [C,R,S,K] transposed weight.
 
     ``res`` ([N,Hi,Wi,C]) is added in the epilogue; ``mask`` ([N,Hi,Wi,C], the forward input when that
     input was a ReLU output) zeroes dx wherever ``mask <= 0`` - the ReLU backward of the producer, applied
-    where the gradient is written instead of by a later pass over it."""
+    where the gradient is written instead of by a later pass over it.
+
+    ``bn_input`` ([N,Hi,Wi,C]) is the pre-normalisation tensor of the BatchNorm that produced the forward
+    input.  With ``bn_scale``/``bn_shift`` (fp32 [C]) that layer's ReLU mask ``bn_input*scale+shift > 0``
+    is applied to dx; with ``bn_sums`` the call returns ``(dx, sums)``, ``sums`` = fp32 ``[2, rows, C]``
+    per-tile partial sums of dx and of dx*bn_input - the two reductions that BatchNorm's backward
+    needs, taken while the gradient tile is still on chip."""
     l = _lib.lib()
     N, Ho, Wo, K = dy.shape
     C, R, S = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[2]
     Hi, Wi = in_hw
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
-    for name, t in (("res", res), ("mask", mask)):
+    for name, t in (("res", res), ("mask", mask), ("bn_input", bn_input)):
         if t is not None and (t.shape != dx.shape or t.dtype != dx.dtype or not t.is_contiguous()):
             raise ValueError(f"dgrad_gpu: {name} must be a contiguous {tuple(dx.shape)} {dx.dtype} tensor")
+    sums = None
+    if bn_sums:
+        if bn_input is None:
+            raise ValueError("dgrad_gpu: bn_sums needs bn_input")
+        rows = l.pda_conv_dgrad_stat_rows(N, Hi, Wi, C, stride[0], stride[1], cfg)
+        sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
     rc = l.pda_conv_igemm(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
-                          _lib.ptr(mask), 0, 0, N, Ho, Wo, K, Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1],
-                          pad[0], pad[1], 0, cfg, 0, _lib.stream())
+                          _lib.ptr(mask), _lib.ptr(bn_input), _lib.ptr(bn_scale), _lib.ptr(bn_shift),
+                          sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
+                          Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, 0,
+                          _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_conv_igemm(dgrad)")
-    return dx
+    return (dx, sums) if bn_sums else dx
 
 
 _WGRAD_WS: dict = {}

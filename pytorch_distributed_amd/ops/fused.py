@@ -15,6 +15,7 @@ ResNet-50 step at ~55 nodes instead of ~175 (reference: the torchvision Bottlene
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -22,11 +23,40 @@ import torch
 from . import _lib, conv as C, norm as Nm, pool as P
 
 
+# Smallest GEMM depth (Cout*R*S of the consuming conv's dgrad) for which the dgrad epilogue also takes the
+# producer's BatchNorm-backward sums: a deep GEMM hides the extra epilogue traffic behind the matrix work of
+# the other resident workgroup, a shallow one (1x1 convs off a narrow layer) is memory-bound already and
+# does better with the stand-alone streaming reduction.
+_SUMS_MIN_K = int(os.environ.get("PDA_FUSE_BN_SUMS_MIN_K", "0"))
+
+
+class BNBackwardLink:
+    """Hand-off between a fused op (the producer) and the ONE fused op that consumes its output.
+
+    The producer, called with ``dout_premasked=True, out_link=link``, records here what the backward of
+    its BatchNorm needs: ``y`` (its conv output before normalisation, ``None`` outside training mode),
+    ``scale``/``shift`` and whether its ReLU mask can be recomputed from ``y`` (``remask``: no residual
+    was added before the ReLU).  The consumer, called with ``in_link=link``, applies the producer's ReLU
+    mask in its own dgrad epilogue and, while the gradient tile is still on chip, also takes the two
+    per-channel sums (``sum g``, ``sum g*y``) that the producer's BatchNorm backward would otherwise get
+    from a separate pass over ``g`` and ``y``; it leaves them in ``sums`` for the producer's backward,
+    which runs next.  ``sums is None`` there (consumer in a fallback path) just means the producer reduces
+    the - already masked - gradient itself."""
+
+    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums")
+
+    def __init__(self):
+        self.y = self.scale = self.shift = self.sums = None
+        self.relu = True
+        self.remask = False
+
+
 class _ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
                 cache: C.WeightCache, passthrough: bool = False, mask_dx: bool = False,
-                dout_premasked: bool = False):
+                dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
+                out_link: Optional[BNBackwardLink] = None):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -58,6 +88,14 @@ class _ConvBnActFn(torch.autograd.Function):
         ctx.beta = beta
         ctx.mask_dx = mask_dx
         ctx.premasked = bool(dout_premasked and relu)
+        ctx.in_link = in_link
+        ctx.out_link = out_link if dout_premasked else None
+        if ctx.out_link is not None:
+            out_link.relu = relu
+            out_link.remask = relu and residual is None
+            out_link.scale, out_link.shift = scale, shift
+            out_link.y = y if train_stats else None
+            out_link.sums = None
         mask_src = out if (relu and not ctx.premasked and (residual is not None or not train_stats)) else None
         ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd, scale, shift, gamma)
         if passthrough:
@@ -72,11 +110,16 @@ class _ConvBnActFn(torch.autograd.Function):
         stride, pad, relu, has_res, count, group, cache, train_stats = ctx.cfg
         dout = dout.contiguous()
         K, Cin, R, S = weight.shape
-        if train_stats and ctx.premasked:
+        presums = None
+        if ctx.out_link is not None:
+            presums, ctx.out_link.sums = ctx.out_link.sums, None
+            ctx.out_link.y = None
+        if train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
-            # residual branch's gradient IS dout
+            # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)
             dy, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False,
-                                        False, group, ctx.beta, cache.stats_buffer(K, dout.device))
+                                        False, group, ctx.beta, cache.stats_buffer(K, dout.device),
+                                        presums=presums)
             dres = dout if has_res else None
         elif train_stats:
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
@@ -92,18 +135,33 @@ class _ConvBnActFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if dalias is not None:
                 dalias = dalias.contiguous()
-            dx = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
-                             res=dalias, mask=x if ctx.mask_dx else None)
-            if dx is None:
+            # what this op does on behalf of the op that produced x (see BNBackwardLink)
+            link = ctx.in_link
+            mask_x = ctx.mask_dx or (link is not None and link.relu)
+            bn_in = sc = sf = None
+            if (link is not None and link.y is not None and link.y.shape == x.shape and link.y.dtype == dy.dtype
+                    and K * R * S >= _SUMS_MIN_K):
+                bn_in = link.y
+                if link.relu and link.remask:
+                    sc, sf, mask_x = link.scale, link.shift, False
+            r = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
+                            res=dalias, mask=x if mask_x else None, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                            bn_sums=bn_in is not None)
+            if r is None:
                 dx = torch.empty_like(x)
                 C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
                               (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
                 if dalias is not None:
                     dx = dx + dalias
-                if ctx.mask_dx:
+                if mask_x or sc is not None:
                     dx = dx * (x > 0).to(dx.dtype)
+            elif bn_in is not None:
+                dx, link.sums = r
+            else:
+                dx = r
         elif dalias is not None:
-            dx = dalias * (x > 0).to(dalias.dtype) if ctx.mask_dx else dalias
+            masked = ctx.mask_dx or (ctx.in_link is not None and ctx.in_link.relu)
+            dx = dalias * (x > 0).to(dalias.dtype) if masked else dalias
         if ctx.needs_input_grad[1]:
             sink = C.grad_sink(weight)
             dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink)
@@ -117,12 +175,13 @@ class _ConvBnActFn(torch.autograd.Function):
                     dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
                 cache: Optional[C.WeightCache] = None, passthrough: bool = False, mask_dx: bool = False,
-                dout_premasked: bool = False):
+                dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
+                out_link: Optional[BNBackwardLink] = None):
     """NHWC fused conv + BatchNorm (+residual) (+ReLU).
 
     ``passthrough=True`` returns ``(out, x_alias)``: feed ``x_alias`` to the other consumer of ``x``
@@ -135,14 +194,19 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: N
     gradient already multiplied by ``x > 0``; the producer, called with ``dout_premasked=True``, then
     skips its own mask: it neither re-reads its output nor writes a separate masked copy for its
     residual branch.  ``dout_premasked`` without a masking consumer gives wrong gradients; ``mask_dx``
-    alone is always correct (masking twice is harmless)."""
+    alone is always correct (masking twice is harmless).
+
+    ``out_link`` (with ``dout_premasked=True``) / ``in_link``: a :class:`BNBackwardLink` shared by this op
+    and the single consumer of its output, through which the consumer's dgrad epilogue also delivers the
+    reductions of this op's BatchNorm backward.  A consumer given ``in_link`` always applies the
+    producer's ReLU mask, so the pair stays correct when the sums cannot be produced."""
     if not x.is_cuda:
         # reference path: the ReLU masks its own gradient, so both hints can be ignored together
         y = C.conv2d_ref(x, weight, None, stride, pad)
         o = Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
         return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
-                              cache or C.WeightCache(), passthrough, mask_dx, dout_premasked)
+                              cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link)
 
 
 class _GradMaskFn(torch.autograd.Function):

@@ -135,8 +135,11 @@ def _vec_sink(param):
 
 
 def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu: bool, want_dres: bool,
-             group=None, beta=None, scratch=None):
+             group=None, beta=None, scratch=None, presums=None):
     """-> dy, dres (or None), dgamma, dbeta.
+
+    ``presums`` (fp32 ``[2, rows, C]``: partial sums of ``dout`` and of ``dout*y``, as returned by
+    ``conv.dgrad_gpu(..., bn_sums=True)``) replaces this function's own reduction pass over dout and y.
 
     When both affine parameters opted into direct gradient accumulation, their gradients are added
     to ``.grad`` by the finalize kernel and ``None`` is returned for them.  ``scratch`` (all-zero fp32
@@ -148,23 +151,33 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     dev = y.device
     n = l.pda_bn_num_partials(M, C, _lib.dt(y))
     slots = 0
-    if scratch is not None and n > scratch.shape[1]:
+    if presums is not None:
+        if presums.shape[0] != 2 or presums.shape[2] != C or presums.dtype != torch.float32 or relu:
+            raise ValueError("norm.backward: presums must be fp32 [2, rows, C] sums of an already masked gradient")
+        n = presums.shape[1]
+        pdg, pdb = presums[1], presums[0]
+    elif scratch is not None and n > scratch.shape[1]:
         part, slots, n = scratch, scratch.shape[1], scratch.shape[1]
+        pdg, pdb = part[0], part[1]
     else:
         part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
-    _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), mean.data_ptr(),
-                                   invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C, int(relu),
-                                   part[0].data_ptr(), part[1].data_ptr(), slots, _lib.stream()), "pda_bn_bwd_reduce")
+        pdg, pdb = part[0], part[1]
+    if presums is None:
+        _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask),
+                                       mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C,
+                                       int(relu), pdg.data_ptr(), pdb.data_ptr(), slots, _lib.stream()),
+                   "pda_bn_bwd_reduce")
     dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
     coef = torch.empty((5, C), device=dev, dtype=torch.float32)
     sync = _world(group) > 1
     sink_g, sink_b = _vec_sink(gamma), _vec_sink(beta)
     direct = sink_g is not None and sink_b is not None
-    _lib.check(l.pda_bn_bwd_finalize(part[0].data_ptr(), part[1].data_ptr(), n, C, dgb[0].data_ptr(),
+    _lib.check(l.pda_bn_bwd_finalize(pdg.data_ptr(), pdb.data_ptr(), n, C, dgb[0].data_ptr(),
                                      dgb[1].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                      shift.data_ptr(), _lib.ptr(gamma), float(count),
                                      0 if sync else coef.data_ptr(), sink_g.data_ptr() if direct else 0,
-                                     sink_b.data_ptr() if direct else 0, int(slots > 0), _lib.stream()),
+                                     sink_b.data_ptr() if direct else 0, int(slots > 0), int(presums is not None),
+                                     _lib.stream()),
                "pda_bn_bwd_finalize")
     if sync:
         import torch.distributed as dist

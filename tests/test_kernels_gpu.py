@@ -497,7 +497,8 @@ def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw, batch):
         assert total > stock_total - 0.05, (total, stock_total, median, cos[:3])
 
 
-@pytest.mark.parametrize("arch,dtype,hw,batch", [("resnet18", torch.float32, 32, 8), ("resnet50", torch.float16, 64, 16),
+@pytest.mark.parametrize("arch,dtype,hw,batch", [("resnet18", torch.float32, 32, 8), ("resnet50", torch.float32, 64, 8),
+                                                 ("resnet50", torch.float16, 64, 16),
                                                  ("resnet50", torch.bfloat16, 64, 16)])
 def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch):
     """Block-output ReLU masks applied in the next block's dgrad epilogue == applied by the owning BatchNorm
@@ -521,9 +522,13 @@ def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch):
             assert not missing, (mode, fuse, missing)
             grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
         for k in grads[0]:
-            # identical arithmetic; only the float-atomic split-K sums of some wgrad launches are
-            # order-dependent from run to run (1e-6-level), a wrong mask would be an O(1) difference
-            assert rel_err(grads[0][k], grads[1][k]) < 1e-4, (mode, k)
+            # same arithmetic, different summation order (per-tile partial sums in the dgrad epilogue vs
+            # per-workgroup ones in the reduce kernel, float-atomic split-K in some wgrads): 1e-6-level in
+            # fp32; in 16-bit a last-bit difference of one gradient tensor is amplified by the layers
+            # below it.  A wrong mask or a wrong sum would be an O(1) difference.
+            assert rel_err(grads[0][k], grads[1][k]) < (1e-4 if dtype == torch.float32 else 0.1), (mode, k)
+        flat = [torch.cat([g[k].float().flatten() for k in g]) for g in grads]
+        assert _cos(flat[0], flat[1]) > (0.999999 if dtype == torch.float32 else 0.999), mode
     m.fuse_relu_backward(True)
     # a forward hook on a block may leak its output to an unknown consumer: that block keeps its own mask
     h = m.layer2[1].register_forward_hook(lambda mod, i, o: None)
@@ -548,6 +553,38 @@ def test_dgrad_mask_epilogue(dtype, stride):
     assert torch.equal(masked, plain * (xm > 0).to(dtype))
     with pytest.raises(ValueError):
         C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), mask=xm[:, :-1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("stride,cfg", [(1, 0), (2, 0), (1, 3), (2, 16)])
+@pytest.mark.parametrize("remask", [False, True])
+def test_dgrad_bn_sums_epilogue(dtype, stride, cfg, remask):
+    """The BatchNorm-backward sums taken in the dgrad epilogue == the same sums of the written tensor."""
+    torch.manual_seed(23)
+    N, H, W, Cin, K = 5, 14, 14, 128, 64
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 24).to(dtype).permute(0, 3, 1, 2)
+    Ho = (H + 2 - 3) // stride + 1
+    dy = torch.randn(N, Ho, Ho, K, device=DEV).to(dtype)
+    res = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    c = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    sc = torch.randn(Cin, device=DEV)
+    sf = torch.randn(Cin, device=DEV) * 0.3
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    plain = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=res, cfg=cfg)
+    if remask:
+        dx, sums = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=res, cfg=cfg, bn_input=c, bn_scale=sc,
+                               bn_shift=sf, bn_sums=True)
+        want = plain * ((c.float() * sc + sf) > 0).to(dtype)
+    else:
+        xm = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+        dx, sums = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=res, cfg=cfg, mask=xm, bn_input=c,
+                               bn_sums=True)
+        want = plain * (xm > 0).to(dtype)
+    assert torch.equal(dx, want)
+    assert sums.shape[0] == 2 and sums.shape[2] == Cin
+    d = dx.double().view(-1, Cin)
+    assert rel_err(sums[0].double().sum(0), d.sum(0)) < 1e-5
+    assert rel_err(sums[1].double().sum(0), (d * c.double().view(-1, Cin)).sum(0)) < 1e-5
 
 
 def test_mnist_net_gpu_matches_cpu():
