@@ -21,11 +21,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--detail", action="store_true", help="also time the epilogue extras one at a time")
+    ap.add_argument("--layer", default="", help="only this layer: H,Cin,Cout,k,s")
     a = ap.parse_args()
     dt, dev = torch.float16, "cuda"
     l = _lib.lib()
     tot = [0.0, 0.0, 0.0]
     for (h, ci, co, k, s), count in resnet50_shapes().items():
+        if a.layer and (h, ci, co, k, s) != tuple(int(v) for v in a.layer.split(",")):
+            continue
         pad, ho = k // 2, h // s
         w = (torch.randn(co, k, k, ci, device=dev) / (k * k * ci) ** 0.5).to(dt)
         wt = C.krsc_to_crsk(w, dt)

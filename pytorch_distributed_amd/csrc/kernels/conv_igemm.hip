@@ -107,7 +107,9 @@ igemm_kernel(ConvArgs a) {
   // operand tiles (two stages); the 16-bit epilogue re-uses the space to stage the output tile
   constexpr int TILE_BYTES = 2 * (BM + BN) * ROWB;
   constexpr int EPI_BYTES = sizeof(T) == 2 ? BM * (BN * (int)sizeof(T) + 16) : 0;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES];
+  constexpr int GRED_BYTES = (EX && sizeof(T) == 2) ? 2 * EPC * (NT + 8) * 4 : 0;  // BatchNorm-backward sums
+  constexpr int LDS_BYTES0 = TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES0 > GRED_BYTES ? LDS_BYTES0 : GRED_BYTES];
   unsigned char* ldsA = lds;
   unsigned char* ldsB = lds + 2 * BM * ROWB;
 
@@ -254,6 +256,63 @@ igemm_kernel(ConvArgs a) {
     }
   };
 
+  // Output vectors of the 16-bit write-out: thread t owns vectors t, t+NT, ... of the BM x (BN/EPC) tile.
+  constexpr int VPR = BN / EPC;      // 16-byte vectors per tile row
+  constexpr int KI = BM * VPR / NT;  // vectors written by one thread
+  static_assert(NT % VPR == 0, "a thread keeps one vector column for all of its rows");
+  auto vec_offset = [&](int mbase, int k, long long& o) -> bool {
+    const int v = t + NT * k;
+    const int row = v / VPR, cv = v % VPR;
+    const int m = mbase + row, n = n0 + cv * EPC;
+    bool rok = m < a.M;
+    long long orow = m;
+    if (PAR) {
+      int pn, pho, pwo;
+      rok = decode(m, pn, pho, pwo);
+      orow = ((long long)pn * a.Ho + pho) * a.Wo + pwo;
+    }
+    const bool ok = rok && n < a.Co;
+    o = ok ? orow * a.Co + n : 0;
+    return ok;
+  };
+  // The BatchNorm operand of the write-out is requested up front: its loads complete under the main loop
+  // (32 registers) instead of stalling the epilogue of a workgroup that has nothing else left to do.
+  constexpr bool VEC16 = sizeof(T) == 2;
+  constexpr int KB = (EX && VEC16) ? KI : 1;
+  Vec16<T> bv[KB];
+  if constexpr (EX && VEC16) {
+    if (a.bnc != nullptr && a.Co % EPC == 0) {
+      const T* __restrict__ Bc0 = reinterpret_cast<const T*>(a.bnc);
+#pragma unroll
+      for (int k = 0; k < KI; ++k) {
+        long long o;
+        vec_offset(m0, k, o);  // a thread without a valid k-th vector reads element 0
+#ifndef PDA_DBG_NO_BV
+        bv[k] = load16(Bc0 + o);
+#else
+        bv[k] = load16(Bc0);
+#endif
+      }
+    }
+  }
+
+  // ... and so are the producer's scale/shift for the 8 columns of this thread (ReLU mask recomputation)
+  float msc[EPC], msf[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { msc[e] = 0.f; msf[e] = 0.f; }
+  if constexpr (EX && VEC16) {
+    const int nc = n0 + (t % VPR) * EPC;
+    if (a.bnc != nullptr && a.bn_scale != nullptr && nc < a.Co && a.Co % EPC == 0) {
+#pragma unroll
+      for (int e = 0; e < EPC; e += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(a.bn_scale + nc + e);
+        const float4 f4 = *reinterpret_cast<const float4*>(a.bn_shift + nc + e);
+        msc[e] = s4.x; msc[e + 1] = s4.y; msc[e + 2] = s4.z; msc[e + 3] = s4.w;
+        msf[e] = f4.x; msf[e + 1] = f4.y; msf[e + 2] = f4.z; msf[e + 3] = f4.w;
+      }
+    }
+  }
+
   f32x16 acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -373,50 +432,30 @@ igemm_kernel(ConvArgs a) {
   // sit in registers for the whole loop and cost a wave of occupancy): hide m0 behind an opaque copy.
   int m0e = m0;
   if (PAR) asm volatile("" : "+v"(m0e));
-  const bool vec_epi = (sizeof(T) == 2) && (a.Co % EPC == 0);
+  // (the instantiations with the epilogue extras only exist in the vector form for 16-bit types: the
+  // host routes a Co that is not a multiple of 8 elsewhere)
+  const bool vec_epi = (sizeof(T) == 2) && (EX || a.Co % EPC == 0);
   if (vec_epi) {
     constexpr int CP = BN * (int)sizeof(T) + 16;  // padded row pitch, keeps 16-byte alignment
-    constexpr int VPR = BN / EPC;                 // 16-byte vectors per tile row
-    constexpr int KI = BM * VPR / NT;             // vectors written by one thread
-    static_assert(NT % VPR == 0, "a thread keeps one vector column for all of its rows");
-    // Everything the write-out reads from global memory (residual, mask, BatchNorm operand) is requested
-    // here, before the accumulators are staged through LDS: all KI vectors of a stream in one batch with
-    // no branch between them (a thread without a valid k-th vector reads element 0 instead), so their
-    // latencies overlap each other and the staging pass instead of adding up per row.
+    // The residual and the mask are requested here, before the accumulators are staged through LDS:
+    // all KI vectors of a stream in one batch with no branch between them (a thread without a valid
+    // k-th vector reads element 0 instead), so their latencies overlap each other and the staging pass
+    // instead of adding up per row.
     constexpr int KE = EX ? KI : 1;
-    long long eo[KE];
-    bool eok[KE];
-    auto vec_offset = [&](int k, long long& o) -> bool {
-      const int v = t + NT * k;
-      const int row = v / VPR, cv = v % VPR;
-      const int m = m0e + row, n = n0 + cv * EPC;
-      bool rok = m < a.M;
-      long long orow = m;
-      if (PAR) {
-        int pn, pho, pwo;
-        rok = decode(m, pn, pho, pwo);
-        orow = ((long long)pn * a.Ho + pho) * a.Wo + pwo;
-      }
-      const bool ok = rok && n < a.Co;
-      o = ok ? orow * a.Co + n : 0;
-      return ok;
-    };
+    long long eo[KE];  // < 0: this thread has no k-th vector
     if constexpr (EX) {
 #pragma unroll
-      for (int k = 0; k < KI; ++k) eok[k] = vec_offset(k, eo[k]);
+      for (int k = 0; k < KI; ++k)
+        if (!vec_offset(m0e, k, eo[k])) eo[k] = -1;
     }
-    Vec16<T> rv[KE], mv[KE], bv[KE];
+    Vec16<T> rv[KE], mv[KE];
     if (Rz != nullptr) {
 #pragma unroll
-      for (int k = 0; k < KE; ++k) rv[k] = load16(Rz + eo[k]);
+      for (int k = 0; k < KE; ++k) rv[k] = load16(Rz + (eo[k] < 0 ? 0 : eo[k]));
     }
     if (Mk != nullptr) {
 #pragma unroll
-      for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + eo[k]);
-    }
-    if (Bc != nullptr) {
-#pragma unroll
-      for (int k = 0; k < KE; ++k) bv[k] = load16(Bc + eo[k]);
+      for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + (eo[k] < 0 ? 0 : eo[k]));
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -437,17 +476,9 @@ igemm_kernel(ConvArgs a) {
         }
       }
     __syncthreads();
-    const int cvt = t % VPR;
-    float g1[EPC], g2[EPC], msc[EPC], msf[EPC];
+    float g1[EPC], g2[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { g1[e] = 0.f; g2[e] = 0.f; msc[e] = 0.f; msf[e] = 0.f; }
-    if (remask && n0 + cvt * EPC < a.Co) {
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        msc[e] = a.bn_scale[n0 + cvt * EPC + e];
-        msf[e] = a.bn_shift[n0 + cvt * EPC + e];
-      }
-    }
+    for (int e = 0; e < EPC; ++e) { g1[e] = 0.f; g2[e] = 0.f; }
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int v = t + NT * k;
@@ -456,9 +487,9 @@ igemm_kernel(ConvArgs a) {
       bool ok;
       if constexpr (EX) {
         o = eo[k];
-        ok = eok[k];
+        ok = o >= 0;
       } else {
-        ok = vec_offset(k, o);
+        ok = vec_offset(m0e, k, o);
       }
       if (ok) {
         Vec16<T> val = *reinterpret_cast<const Vec16<T>*>(lds + row * CP + cv * 16);
@@ -491,28 +522,40 @@ igemm_kernel(ConvArgs a) {
       }
     }
     if (stats) __syncthreads();  // the statistics scratch below reuses the staging area
+#ifdef PDA_DBG_NO_GRED
+    if (gstats) {
+      float z = 0.f;
+      for (int e = 0; e < EPC; ++e) z += g1[e] + g2[e];
+      if (z == 12345.f) a.psum[0] = z;
+      return;
+    }
+#endif
     if (gstats) {
       // threads t, t+VPR, t+2*VPR, ... hold the same 8 columns: fold them through LDS
-      float* gred = reinterpret_cast<float*>(lds);  // [NT/VPR][BN][2]
-      const int grp = t / VPR;
+      // image [2][EPC][NT + 8]: element e of thread t at e*(NT+8) + t, so the writes (consecutive t) and
+      // the reads below (lane -> e = t%EPC, vector t/EPC: banks e*8 + t/EPC) are both conflict-free
+      float* gred = reinterpret_cast<float*>(lds);
+      constexpr int GS = NT + 8;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        gred[((grp * BN) + cvt * EPC + e) * 2 + 0] = g1[e];
-        gred[((grp * BN) + cvt * EPC + e) * 2 + 1] = g2[e];
+        gred[e * GS + t] = g1[e];
+        gred[(EPC + e) * GS + t] = g2[e];
       }
       __syncthreads();
       if (t < BN && n0 + t < a.Co) {
         float v1 = 0.f, v2 = 0.f;
+        const int e = t % EPC, cvx = t / EPC;
+#pragma unroll 4
         for (int w = 0; w < NT / VPR; ++w) {
-          v1 += gred[(w * BN + t) * 2];
-          v2 += gred[(w * BN + t) * 2 + 1];
+          v1 += gred[e * GS + w * VPR + cvx];
+          v2 += gred[(EPC + e) * GS + w * VPR + cvx];
         }
         a.psum[(long long)prow * a.Co + n0 + t] = v1;
         a.psq[(long long)prow * a.Co + n0 + t] = v2;
       }
       return;
     }
-  } else {
+  } else if constexpr (!(EX && sizeof(T) == 2)) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -948,6 +991,7 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
   constexpr int NT = BM >= 256 ? 512 : 256;
   const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
+  if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
   if (dgrad == MODE_DGRAD_S2) {
     if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, true>), dim3(4 * tiles), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, false>), dim3(4 * tiles), dim3(NT), 0, st, a);
@@ -1049,6 +1093,8 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
     a.M = N * a.Ha * a.Wb;
   }
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -5;
+  if ((((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) != 0) return -5;
+  if ((((uintptr_t)res | (uintptr_t)mask | (uintptr_t)bnc) & 15) != 0) return -5;
   switch (dtype) {
     case PDA_F16: return dispatch_igemm<f16>(a, dgrad, cfg, stream);
     case PDA_BF16: return dispatch_igemm<bf16>(a, dgrad, cfg, stream);

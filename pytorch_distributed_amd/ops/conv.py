@@ -130,6 +130,20 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
                           sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
                           Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, 0,
                           _lib.stream())
+    if rc == -8:
+        # 16-bit dX whose channel count is not a multiple of 8: the epilogue extras only exist in the
+        # vector write-out, so run the plain kernel and apply them with tensor ops (no sums: the caller's
+        # BatchNorm backward then reduces by itself)
+        dx = dgrad_gpu(dy, w_crsk, in_hw, stride, pad, cfg=cfg)
+        if dx is None:
+            return None
+        if res is not None:
+            dx += res
+        if mask is not None:
+            dx *= (mask > 0).to(dx.dtype)
+        if bn_input is not None and bn_scale is not None:
+            dx *= ((bn_input.float() * bn_scale + bn_shift) > 0).to(dx.dtype)
+        return (dx, None) if bn_sums else dx
     if rc < 0:
         return None
     _lib.check(rc, "pda_conv_igemm(dgrad)")
