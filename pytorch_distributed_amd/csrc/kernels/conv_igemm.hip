@@ -287,11 +287,7 @@ igemm_kernel(ConvArgs a) {
       for (int k = 0; k < KI; ++k) {
         long long o;
         vec_offset(m0, k, o);  // a thread without a valid k-th vector reads element 0
-#ifndef PDA_DBG_NO_BV
         bv[k] = load16(Bc0 + o);
-#else
-        bv[k] = load16(Bc0);
-#endif
       }
     }
   }
@@ -522,14 +518,6 @@ igemm_kernel(ConvArgs a) {
       }
     }
     if (stats) __syncthreads();  // the statistics scratch below reuses the staging area
-#ifdef PDA_DBG_NO_GRED
-    if (gstats) {
-      float z = 0.f;
-      for (int e = 0; e < EPC; ++e) z += g1[e] + g2[e];
-      if (z == 12345.f) a.psum[0] = z;
-      return;
-    }
-#endif
     if (gstats) {
       // threads t, t+VPR, t+2*VPR, ... hold the same 8 columns: fold them through LDS
       // image [2][EPC][NT + 8]: element e of thread t at e*(NT+8) + t, so the writes (consecutive t) and
