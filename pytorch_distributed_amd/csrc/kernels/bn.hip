@@ -132,6 +132,48 @@ struct PartialReduce {
   }
 };
 
+// [nparts][C] partial rows -> [gridDim.y][C]: workgroup (cg, rs) adds rows rs*chunk ... of 32 channels
+// (128-byte coalesced row segments, 8 row lanes, fp64 accumulation).  Run ahead of a finalize-type kernel
+// when there are thousands of partial rows (one per conv tile in the early ResNet stages at large batch):
+// those kernels give each channel group ONE workgroup, which then walks every row alone.
+__global__ void __launch_bounds__(256)
+bn_compress_partials_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C,
+                            int chunk, float* __restrict__ oa, float* __restrict__ ob) {
+  __shared__ double red[2][8][33];
+  const int lc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
+  const int r0 = blockIdx.y * chunk;
+  const int r1 = r0 + chunk < nparts ? r0 + chunk : nparts;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    int r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {
+      const float a0 = pa[(long long)r * C + c], a1 = pa[(long long)(r + 8) * C + c];
+      const float a2 = pa[(long long)(r + 16) * C + c], a3 = pa[(long long)(r + 24) * C + c];
+      const float b0 = pb[(long long)r * C + c], b1 = pb[(long long)(r + 8) * C + c];
+      const float b2 = pb[(long long)(r + 16) * C + c], b3 = pb[(long long)(r + 24) * C + c];
+      a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < r1; r += 8) {
+      a += (double)pa[(long long)r * C + c];
+      b += (double)pb[(long long)r * C + c];
+    }
+  }
+  red[0][rl][lc] = a;
+  red[1][rl][lc] = b;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      a += red[0][k][lc];
+      b += red[1][k][lc];
+    }
+    oa[(long long)blockIdx.y * C + c] = (float)a;
+    ob[(long long)blockIdx.y * C + c] = (float)b;
+  }
+}
+
 // channels per block for the finalize-type kernels
 static inline int partial_ch(int nparts, int C) { return (nparts > 512 && C < 16 * 96) ? 4 : 16; }
 
@@ -484,6 +526,25 @@ PDA_EXPORT int pda_bn_reduce_partials(float* psum, float* psq, int nparts, int C
   else
     hipLaunchKernelGGL(bn_reduce_partials_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C,
                        sums, clear);
+  return pda_check_launch();
+}
+
+// Rows a compression pass should leave for nparts partial rows (0: not worth a pass).
+PDA_EXPORT int pda_bn_compress_rows(int nparts, int C) {
+  if (nparts < 1024) return 0;
+  int rs = nparts / 32;  // >= 32 rows per workgroup
+  const int cap = 2048 / ((C + 31) / 32) > 8 ? 2048 / ((C + 31) / 32) : 8;  // ~2048 workgroups at most
+  if (rs > cap) rs = cap;
+  if (rs > 128) rs = 128;
+  return rs;
+}
+
+PDA_EXPORT int pda_bn_compress_partials(const float* pa, const float* pb, int nparts, int C, float* oa, float* ob,
+                                        int rs, hipStream_t st) {
+  if (rs < 1 || nparts < 1) return -1;
+  const int chunk = (nparts + rs - 1) / rs;
+  hipLaunchKernelGGL(bn_compress_partials_kernel, dim3((C + 31) / 32, rs), dim3(256), 0, st, pa, pb, nparts, C,
+                     chunk, oa, ob);
   return pda_check_launch();
 }
 

@@ -41,6 +41,8 @@ _SIGS = {
     "pda_bn_num_partials": [c_ll, c_i, c_i],
     "pda_bn_stats_partial": [c_i, c_p, c_ll, c_i, c_p, c_p, c_p],
     "pda_bn_reduce_partials": [c_p, c_p, c_i, c_i, c_p, c_i, c_p],
+    "pda_bn_compress_rows": [c_i, c_i],
+    "pda_bn_compress_partials": [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p],
     "pda_bn_finalize": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "pda_bn_eval_coeffs": [c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "pda_bn_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],

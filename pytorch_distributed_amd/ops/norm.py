@@ -51,6 +51,21 @@ def stats_partials(y2d: torch.Tensor):
     return part[0], part[1]
 
 
+def compress_partials(pa: torch.Tensor, pb: torch.Tensor):
+    """Thousands of per-tile partial rows ``[n, C]`` (x2) -> at most 128 rows, with a wide launch; the
+    finalize-type kernels reduce whatever they are given with one workgroup per channel group, which is the
+    right shape for tens of rows and a slow one for ten thousand.  Returns the inputs when n is small."""
+    l = _lib.lib()
+    n, C = pa.shape
+    rs = l.pda_bn_compress_rows(n, C)
+    if rs <= 0:
+        return pa, pb
+    out = torch.empty((2, rs, C), device=pa.device, dtype=torch.float32)
+    _lib.check(l.pda_bn_compress_partials(pa.data_ptr(), pb.data_ptr(), n, C, out[0].data_ptr(), out[1].data_ptr(),
+                                          rs, _lib.stream()), "pda_bn_compress_partials")
+    return out[0], out[1]
+
+
 def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = False):
     """partials -> (mean, invstd, scale, shift); updates running stats in place.
 
@@ -58,6 +73,8 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = Fa
     ``conv.WeightCache.stats_buffer``)."""
     l = _lib.lib()
     C = psum.shape[-1]
+    if not clear:
+        psum, psq = compress_partials(psum, psq)
     nparts = psum.shape[0]
     dev = psum.device
     world = _world(st.group)
@@ -154,8 +171,8 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     if presums is not None:
         if presums.shape[0] != 2 or presums.shape[2] != C or presums.dtype != torch.float32 or relu:
             raise ValueError("norm.backward: presums must be fp32 [2, rows, C] sums of an already masked gradient")
-        n = presums.shape[1]
-        pdg, pdb = presums[1], presums[0]
+        pdg, pdb = compress_partials(presums[1], presums[0])
+        n = pdg.shape[0]
     elif scratch is not None and n > scratch.shape[1]:
         part, slots, n = scratch, scratch.shape[1], scratch.shape[1]
         pdg, pdb = part[0], part[1]

@@ -587,6 +587,50 @@ def test_dgrad_bn_sums_epilogue(dtype, stride, cfg, remask):
     assert rel_err(sums[1].double().sum(0), (d * c.double().view(-1, Cin)).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("n,c", [(5000, 96), (1024, 64), (40000, 256), (700, 64)])
+def test_compress_partials(n, c):
+    from pytorch_distributed_amd.ops import norm as Nm
+    torch.manual_seed(31)
+    pa, pb = torch.randn(n, c, device=DEV), torch.rand(n, c, device=DEV)
+    qa, qb = Nm.compress_partials(pa, pb)
+    if n < 1024:
+        assert qa is pa and qb is pb
+        return
+    assert qa.shape[0] <= 128 and qa.shape[1] == c
+    assert rel_err(qa.double().sum(0), pa.double().sum(0)) < 1e-6
+    assert rel_err(qb.double().sum(0), pb.double().sum(0)) < 1e-6
+
+
+def test_two_fused_layers_many_tiles():
+    """Large M (thousands of tiles): statistics partials go through the compression pass, forward and
+    backward (the second conv's dgrad epilogue delivers the first layer's BatchNorm-backward sums)."""
+    from pytorch_distributed_amd.ops.fused import BNBackwardLink
+    torch.manual_seed(32)
+    N, H, Cc = 48, 56, 64
+    c1, b1 = pnn.Conv2d(Cc, Cc, 3, 1, 1, bias=False).to(DEV), pnn.BatchNorm2d(Cc).to(DEV)
+    c2, b2 = pnn.Conv2d(Cc, Cc, 1, 1, 0, bias=False).to(DEV), pnn.BatchNorm2d(Cc).to(DEV)
+    rc1, rb1 = torch.nn.Conv2d(Cc, Cc, 3, 1, 1, bias=False).to(DEV), torch.nn.BatchNorm2d(Cc).to(DEV)
+    rc2, rb2 = torch.nn.Conv2d(Cc, Cc, 1, 1, 0, bias=False).to(DEV), torch.nn.BatchNorm2d(Cc).to(DEV)
+    for a_, b_ in ((c1, rc1), (b1, rb1), (c2, rc2), (b2, rb2)):
+        b_.load_state_dict(a_.state_dict())
+    x = torch.randn(N, H, H, Cc, device=DEV, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    link = BNBackwardLink()
+    h = pnn.ConvBnAct.run(c1, b1, x, relu=True, dout_premasked=True, out_link=link)
+    out = pnn.ConvBnAct.run(c2, b2, h, relu=True, in_link=link)
+    ref = torch.relu(rb2(rc2(torch.relu(rb1(rc1(xr.permute(0, 3, 1, 2))))))).permute(0, 2, 3, 1)
+    assert rel_err(out, ref) < 1e-3
+    g = torch.randn_like(ref)
+    out.backward(g)
+    ref.backward(g)
+    assert link.sums is None and link.y is None  # consumed and released by the producer's backward
+    assert rel_err(x.grad, xr.grad) < 2e-3
+    for m, r in ((c1, rc1), (b1, rb1), (c2, rc2), (b2, rb2)):
+        for (k, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
+            assert rel_err(p.grad, q.grad) < 2e-3, k
+    assert rel_err(b1.running_var, rb1.running_var) < 1e-4
+
+
 def test_mnist_net_gpu_matches_cpu():
     torch.manual_seed(13)
     net = models.Net().eval()
