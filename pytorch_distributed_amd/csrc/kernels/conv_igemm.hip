@@ -19,6 +19,7 @@
 // fragment reads are bank-conflict free.  wgrad reduces over pixels, which is
 // the strided dimension of both operands, so its fragments come from
 // ds_read_b64_tr_b16 (hardware transposing LDS read) for the 16-bit types.
+#include <cstdlib>
 #include "common.h"
 
 struct ConvArgs {
@@ -1006,13 +1007,26 @@ static int pick_tile(int M, int Co, int cfg) {
   return tile;
 }
 
+static const long long kShallowK = [] {
+  const char* e = getenv("PDA_IGEMM_SHALLOW_K");
+  return e ? atoll(e) : 576LL;
+}();
+
 template <typename T>
 static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st) {
   constexpr int ES = sizeof(T);
   const bool k128 = (a.Ci % (128 / ES)) == 0;
   const bool k64 = (a.Ci % (64 / ES)) == 0;
   if (!k64) return -1;
-  const bool use128 = k128 && (cfg & 8) == 0;
+  // shallow GEMMs (K = R*S*Ci up to 576: the 1x1 convs off 64..256 channels and the 3x3 on 64) run a
+  // handful of K steps at most; 32-deep steps halve the LDS tile (more workgroups per CU) and give even a
+  // K = 64 layer two pipelined steps instead of one load -> compute -> store sequence (measured per layer
+  // on the ResNet-50 shapes, fp16: 5-25 % faster there, slower from K = 1024 up)
+  // (not with the epilogue extras: that instantiation sits at two waves per SIMD either way, and measured
+  // slightly slower with the short steps)
+  const bool extras = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
+  const bool shallow = ES == 2 && (cfg & 7) == 0 && !extras && (long long)a.R * a.S * a.Ci <= kShallowK;
+  const bool use128 = k128 && (cfg & 8) == 0 && !shallow;
   switch (pick_tile(a.M, a.Co, cfg)) {
     case 1: return use128 ? launch_igemm<T, 128, 128, 128>(a, dgrad, st) : launch_igemm<T, 128, 128, 64>(a, dgrad, st);
     case 2: return use128 ? launch_igemm<T, 128, 64, 128>(a, dgrad, st) : launch_igemm<T, 128, 64, 64>(a, dgrad, st);
