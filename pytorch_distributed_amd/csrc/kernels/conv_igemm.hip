@@ -1170,7 +1170,8 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     // 16-bit: the 128x128 tile also wins when one side is only 64 wide (the 64-channel layers at 56x56,
     // 16-20 % faster than 64x64 there: half as many workgroups re-read the pixel stream); 64x64 only for
     // the 64 -> 64 1x1.  fp32 keeps 128x128 for exact multiples.
-    if (es == 2) tile = (Co <= 64 && a.Ktot <= 64) ? 2 : 1;
+    // (and 64 output channels over a deep K - the 3x3 on 64 channels - take the 64(Co) x 128 tile)
+    if (es == 2) tile = Co <= 64 ? (a.Ktot <= 64 ? 2 : a.Ktot > 256 ? 3 : 1) : 1;
     else tile = (Co % 128 == 0 && a.Ktot % 128 == 0) ? 1 : 2;
   }
   bool bk32 = (cfg & 8) != 0;
