@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--detail", action="store_true", help="also time the epilogue extras one at a time")
     ap.add_argument("--layer", default="", help="only this layer: H,Cin,Cout,k,s")
+    ap.add_argument("--cfgs", default="0", help="tile cfgs to time for the fused variant")
     a = ap.parse_args()
     dt, dev = torch.float16, "cuda"
     l = _lib.lib()
@@ -37,8 +38,11 @@ def main():
         sc = torch.randn(ci, device=dev)
         sf = torch.randn(ci, device=dev)
         t0 = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad)), a.iters)
-        t1 = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), bn_input=c, bn_scale=sc, bn_shift=sf,
-                                        bn_sums=True), a.iters)
+        t1s = []
+        for cfg in [int(v) for v in a.cfgs.split(",")]:
+            t1s.append((timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), bn_input=c, bn_scale=sc,
+                                                   bn_shift=sf, bn_sums=True, cfg=cfg), a.iters), cfg))
+        t1 = t1s[0][0]
         if a.detail:
             tr = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), res=c), a.iters)
             tm = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), bn_input=c, bn_scale=sc, bn_shift=sf),
@@ -54,7 +58,8 @@ def main():
                                                 sc.data_ptr(), sf.data_ptr(), M, ci, 1, part[0].data_ptr(),
                                                 part[1].data_ptr(), 0, _lib.stream()), a.iters)
         print(f"H{h:3d} {ci:4d}->{co:4d} k{k} s{s} x{count}: dgrad {t0:6.1f}  +sums {t1:6.1f}  reduce {t2:6.1f}  "
-              f"saving {t0 + t2 - t1:+6.1f} us  (dX channels {ci}, gemm K {co * k * k})", flush=True)
+              f"saving {t0 + t2 - t1:+6.1f} us  (dX channels {ci}, gemm K {co * k * k})  "
+              + " ".join(f"{c_}:{t_:.0f}" for t_, c_ in t1s), flush=True)
         tot[0] += t0 * count
         tot[1] += t1 * count
         tot[2] += t2 * count

@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from .store import TCPStore, FileStore, PrefixStore, Store, StoreTimeout, store_barrier, Heartbeat  # noqa: F401
 
-_STATE = {"store": None, "info": None, "heartbeat": None}
+_STATE = {"store": None, "info": None, "heartbeat": None, "p2p": None, "p2p_tried": False}
 
 
 @dataclass
@@ -204,12 +204,47 @@ def destroy_process_group() -> None:
     if _STATE["heartbeat"] is not None:
         _STATE["heartbeat"].stop()
         _STATE["heartbeat"] = None
+    if _STATE.get("p2p") is not None:
+        _STATE["p2p"].close()   # collective: every rank leaves together, nobody frees a region in use
+        _STATE["p2p"] = None
+    _STATE["p2p_tried"] = False
     if dist.is_initialized():
         dist.destroy_process_group()
     st = _STATE["store"]
     _STATE["store"] = None
     if st is not None:
         st.close()
+
+
+def enable_p2p_small_allreduce(max_elems: int = 65536, timeout_ms: int = 2000):
+    """Route :func:`small_all_reduce` through the one-shot peer-memory kernel (``comm/p2p.py``) instead of
+    an RCCL call.  Collective over the default group; single-node jobs with one process per GPU only.
+    Also switched on by ``PDA_P2P_SMALL=1`` at the first :func:`small_all_reduce`."""
+    from .p2p import P2PAllReduce
+    if _STATE.get("p2p") is None and dist.is_initialized() and dist.get_world_size() > 1:
+        st = _STATE["store"]
+        _STATE["p2p"] = P2PAllReduce(dist.get_rank(), dist.get_world_size(),
+                                     store=PrefixStore("p2p", st) if st is not None else None,
+                                     max_elems=max_elems, timeout_ms=timeout_ms)
+    return _STATE.get("p2p")
+
+
+def small_all_reduce(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
+    """In-place all-reduce of a small tensor (metric vector, SyncBatchNorm statistics): the peer-memory
+    one-shot kernel when it is enabled and applicable (default group, contiguous fp32 device tensor within
+    its message bound), ``torch.distributed`` otherwise.  ``op``: ``"sum"`` or ``"avg"``."""
+    if (group is None or group is dist.group.WORLD) and t.is_cuda:
+        p2p = _STATE.get("p2p")
+        if p2p is None and os.environ.get("PDA_P2P_SMALL", "0") == "1" and not _STATE.get("p2p_tried"):
+            _STATE["p2p_tried"] = True
+            p2p = enable_p2p_small_allreduce()
+        if (p2p is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= p2p.max_elems
+                and t.device == p2p.device):
+            return p2p.all_reduce(t, op)
+    dist.all_reduce(t, group=group)
+    if op == "avg":
+        t /= dist.get_world_size(group)
+    return t
 
 
 def get_rank() -> int:
@@ -226,5 +261,6 @@ def barrier() -> None:
 
 
 __all__ = ["RankInfo", "discover", "slurm_world", "init_process_group", "destroy_process_group", "native_store",
+           "enable_p2p_small_allreduce", "small_all_reduce",
            "rank_info", "get_rank", "get_world_size", "barrier", "TCPStore", "FileStore", "PrefixStore", "Store",
            "StoreTimeout", "store_barrier", "Heartbeat", "C10dStoreAdapter"]

@@ -84,7 +84,8 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = Fa
         _lib.check(l.pda_bn_reduce_partials(psum.data_ptr(), psq.data_ptr(), nparts, C, sums.data_ptr(),
                                             int(clear), _lib.stream()), "pda_bn_reduce_partials")
         clear = False
-        dist.all_reduce(sums, group=st.group)
+        from ..comm import small_all_reduce   # [2, C] floats: the latency path when it is enabled
+        small_all_reduce(sums, "sum", st.group)
         # every rank of a data-parallel job runs the same per-rank batch, so the global
         # element count is known on the host and no device->host read is needed
         count = count * world
@@ -199,7 +200,8 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     if sync:
         import torch.distributed as dist
         tot = dgb.clone()
-        dist.all_reduce(tot, group=group)  # dx needs the global sums; the parameter grads stay local
+        from ..comm import small_all_reduce
+        small_all_reduce(tot, "sum", group)  # dx needs the global sums; the parameter grads stay local
         _lib.check(l.pda_bn_bwd_coefs(tot[0].data_ptr(), tot[1].data_ptr(), C, mean.data_ptr(), invstd.data_ptr(),
                                       scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma), float(count),
                                       coef.data_ptr(), _lib.stream()), "pda_bn_bwd_coefs")

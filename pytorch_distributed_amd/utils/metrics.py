@@ -54,6 +54,6 @@ def reduce_mean_many(tensors: Sequence[torch.Tensor], group=None) -> List[torch.
     import torch.distributed as dist
     packed = torch.stack([t.detach().float().reshape(()) for t in tensors])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(packed, group=group)
-        packed /= dist.get_world_size(group)
+        from ..comm import small_all_reduce
+        small_all_reduce(packed, "avg", group)
     return list(packed.unbind(0))

@@ -1,0 +1,62 @@
+"""P2PAllReduce (one-shot all-reduce through IPC-mapped peer memory) with several processes on one GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "workers", "p2p_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_p2p_allreduce_single_rank():
+    import torch
+    from pytorch_distributed_amd.comm.p2p import P2PAllReduce
+    ar = P2PAllReduce(0, 1, store=None, max_elems=1024)
+    t = torch.randn(1000, device="cuda")
+    ref = t.clone()
+    assert torch.equal(ar.all_reduce(t, "sum"), ref)
+    assert torch.equal(ar.all_reduce(t, "avg"), ref)
+    with pytest.raises(ValueError):
+        ar.all_reduce(torch.zeros(2000, device="cuda"))
+    ar.check()
+    ar.close()
+
+
+def _run_ranks(worker, world):
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=240)
+            outs.append(o)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r}: OK" in o, (r, o[-2000:])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_allreduce_processes_on_one_gpu(world):
+    _run_ranks(WORKER, world)
+
+
+def test_syncbn_statistics_over_p2p():
+    """SyncBatchNorm forward/backward == BatchNorm over the concatenated batch, with the [2, C] statistics
+    reduced by the peer-memory kernel (PDA_P2P_SMALL=1) under a gloo process group."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "p2p_syncbn_worker.py"), 2)
