@@ -153,6 +153,43 @@ class DistributedDataParallel(nn.Module):
             raise RuntimeError(f"rank {self.rank}: parameter shapes differ from rank 0's "
                                "(DistributedDataParallel needs identical replicas)")
 
+    def _broadcast_buffers_cached(self, bufs: List[torch.Tensor]) -> None:
+        """The per-forward buffer broadcast with everything that does not change from step to step kept:
+        one persistent flat buffer per dtype, the device address tables of the pack / unpack launches, and
+        a multi-tensor copy for the integer buffers (53 ``num_batches_tracked`` scalars in a ResNet-50 are
+        one launch each way instead of 53 eight-byte copies)."""
+        key = tuple(b.data_ptr() for b in bufs)
+        plan = getattr(self, "_buf_plan", None)
+        if plan is None or plan[0] != key:
+            groups = []
+            by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+            for t in bufs:
+                by_dtype.setdefault(t.dtype, []).append(t.detach())
+            for dt, ts in by_dtype.items():
+                flat = torch.empty(sum(t.numel() for t in ts), device=ts[0].device, dtype=dt)
+                views, off = [], 0
+                for t in ts:
+                    views.append(flat[off:off + t.numel()].view(t.shape) if t.is_contiguous()
+                                 else flat[off:off + t.numel()])
+                    off += t.numel()
+                if dt in (torch.float32, torch.float16, torch.bfloat16) and ts[0].is_cuda:
+                    phys = [_physical_flat(t) for t in ts]
+                    fviews = [v.reshape(-1) for v in views]
+                    groups.append(("mt", flat, mt.TensorLists([phys, fviews]), mt.TensorLists([fviews, phys])))
+                else:
+                    groups.append(("foreach", flat, ts, views))
+            plan = (key, groups)
+            self._buf_plan = plan
+        for kind, flat, a, b in plan[1]:
+            if kind == "mt":
+                mt.scale(a, 1.0)
+                self._coll.broadcast(flat, 0)
+                mt.scale(b, 1.0)
+            else:
+                torch._foreach_copy_(b, a)
+                self._coll.broadcast(flat, 0)
+                torch._foreach_copy_(a, b)
+
     def _broadcast_coalesced(self, tensors: List[torch.Tensor]) -> None:
         """rank 0 -> all, one flat buffer per dtype (flatten / unflatten are single launches)."""
         if not self._active or not tensors:
@@ -292,7 +329,7 @@ class DistributedDataParallel(nn.Module):
             bufs = [b for b in self.module.buffers()]
             if bufs:
                 with torch.no_grad():
-                    self._broadcast_coalesced(bufs)
+                    self._broadcast_buffers_cached(bufs)
         return self.module(*inputs, **kwargs)
 
     @contextlib.contextmanager
