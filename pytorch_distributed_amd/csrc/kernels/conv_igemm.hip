@@ -319,32 +319,6 @@ igemm_kernel(ConvArgs a) {
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int nk = nr * ns * (a.Ci / BK);  // 0 for a parity class no tap reaches (e.g. 1x1 stride 2)
-#ifdef PDA_WRITE_AFTER_BARRIER
-  // Staging order: the registers hold tile t+1 when step t starts (loaded during step t-1).  It is
-  // written to the idle LDS buffer right after the barrier, the loads for tile t+2 are issued, and
-  // only then do the MFMAs of tile t run - so the LDS stores and the global-load latency both sit
-  // behind a full step of matrix work instead of between the MFMAs and the barrier.
-  if (nk > 0) {
-    gload();
-    lstore(0);
-    if (nk > 1) {
-      advance();
-      gload();
-    }
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = false;  // (stores are issued up front in this ordering)
-    if (kt + 1 < nk) {
-      lstore((kt + 1) & 1);
-      if (kt + 2 < nk) {
-        advance();
-        gload();
-      }
-    }
-    const unsigned char* A_ = ldsA + (kt & 1) * BM * ROWB;
-#else
   if (nk > 0) {
     gload();
     lstore(0);
@@ -358,7 +332,6 @@ igemm_kernel(ConvArgs a) {
       gload();
     }
     const unsigned char* A_ = ldsA + (kt & 1) * BM * ROWB;
-#endif
     const unsigned char* B_ = ldsB + (kt & 1) * BN * ROWB;
     if constexpr (sizeof(T) == 2) {
       typedef typename Mfma32<T>::frag frag;
@@ -794,22 +767,6 @@ wgrad_kernel(WgradArgs a) {
     }
   }
   const int nsteps = (live && mend > mbeg) ? (mend - mbeg + BKP - 1) / BKP : 0;
-#ifdef PDA_WRITE_AFTER_BARRIER
-  if (nsteps > 0) {
-    gload(mbeg);
-    lstore(0);
-    if (nsteps > 1) gload(mbeg + BKP);
-  }
-  __syncthreads();
-
-  const int li = lane & 15, lg = lane >> 4;
-  for (int st = 0; st < nsteps; ++st) {
-    const bool more = false;  // same staging order as the igemm kernel: store t+1, load t+2, then MFMAs of t
-    if (st + 1 < nsteps) {
-      lstore((st + 1) & 1);
-      if (st + 2 < nsteps) gload(mbeg + (st + 2) * BKP);
-    }
-#else
   if (nsteps > 0) {
     gload(mbeg);
     lstore(0);
@@ -820,7 +777,6 @@ wgrad_kernel(WgradArgs a) {
   for (int st = 0; st < nsteps; ++st) {
     const bool more = st + 1 < nsteps;
     if (more) gload(mbeg + (st + 1) * BKP);
-#endif
     const unsigned char* Yb = ldsY + (st & 1) * BKP * PY;
     const unsigned char* Xb = ldsX + (st & 1) * BKP * PX;
     if constexpr (sizeof(T) == 2) {
