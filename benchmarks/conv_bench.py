@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--only", default="fdw", help="which of f(prop) d(grad) w(grad) to time")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default="")
+    ap.add_argument("--no-stats", action="store_true", help="fprop without the BatchNorm statistics epilogue")
     a = ap.parse_args()
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype]
     es = 2 if dt != torch.float32 else 4
@@ -77,7 +78,7 @@ def main():
         best = {}
         for cfg in [int(c) for c in a.cfgs.split(",")]:
             if "f" in a.only:
-                t = timeit(lambda: C.fprop_gpu(x, w, (s, s), (pad, pad), stats=True, cfg=cfg), a.iters)
+                t = timeit(lambda: C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=cfg), a.iters)
                 best.setdefault("fprop", []).append((t, cfg))
             if "d" in a.only:
                 t = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg), a.iters)
