@@ -89,9 +89,9 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 // EX: the epilogue extras (res, mask, bnc) are compiled in; the plain instantiation keeps the lean
 // write-out (the extras cost registers and scalar state even when their pointers are null).
 template <typename T, int BM, int BN, int ROWB, int MODE, bool EX>
-__global__ void __launch_bounds__(BM >= 256 ? 512 : 256) PDA_IGEMM_ATTR
+__global__ void __launch_bounds__(256) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
-  constexpr int WM = BM >= 256 ? 4 : 2;    // waves along M (x 2 along N); 256-row tiles run 8 waves
+  constexpr int WM = 2;                    // 2 x 2 waves; a 256-row tile gives each wave 128 x 64 outputs
   constexpr int NT = 128 * WM;             // threads per workgroup
   constexpr bool DGRAD = MODE != MODE_FPROP;
   constexpr bool PAR = MODE == MODE_DGRAD_S2;
@@ -934,7 +934,7 @@ static int ilog2_exact(int v) {
 template <typename T, int BM, int BN, int ROWB>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
-  constexpr int NT = BM >= 256 ? 512 : 256;
+  constexpr int NT = 256;
   const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
   if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
   if (dgrad == MODE_DGRAD_S2) {
@@ -950,13 +950,26 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   return pda_check_launch();
 }
 
-// cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves); bit 3 forces
-// 64-byte K rows.
-static int pick_tile(int M, int Co, int cfg) {
+// Fewest 256x128 tiles for which the big tile is chosen automatically (0 = never, the default: the
+// per-layer gain below did not show in the ResNet-50 step time, 10.56-10.62k vs 10.59k images/s).
+static const long long kBigTiles = [] {
+  const char* e = getenv("PDA_IGEMM_BIG_TILES");
+  return e ? atoll(e) : 0LL;
+}();
+
+// cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (each of the 2x2 waves owns
+// 128x64 outputs); bit 3 forces 64-byte K rows.
+// big_ok: 16-bit plain kernel.  The 128x128 tile is bound by LDS traffic (every wave re-reads a 64-row A
+// and a 64-row B slice per 16 MFMAs); a 128x64 wave tile moves 25 % fewer LDS bytes per MFMA and measured
+// 5-10 % faster in isolation on the deep layers at 28x28 and 14x14 - as long as there are enough tiles to fill the chip
+// twice, and with 32-deep K steps (the 64-deep version needs 96 KB of LDS: one workgroup per CU).
+static int pick_tile(int M, int Co, int cfg, bool big_ok = false) {
   int tile = cfg & 7;
   if (tile == 0) {
     const long long t128 = (long long)((M + 127) / 128) * ((Co + 127) / 128);
-    if (Co <= 64) tile = 2;
+    const long long t256 = (long long)((M + 255) / 256) * ((Co + 127) / 128);
+    if (big_ok && kBigTiles > 0 && Co % 128 == 0 && t256 >= kBigTiles) tile = 4;
+    else if (Co <= 64) tile = 2;
     else if (t128 < 192 && M >= 64) tile = (Co % 128 == 0 && t128 * 2 >= 192) ? 2 : 3;
     else tile = 1;
   }
@@ -982,8 +995,10 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   // slightly slower with the short steps)
   const bool extras = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
   const bool shallow = ES == 2 && (cfg & 7) == 0 && !extras && (long long)a.R * a.S * a.Ci <= kShallowK;
-  const bool use128 = k128 && (cfg & 8) == 0 && !shallow;
-  switch (pick_tile(a.M, a.Co, cfg)) {
+  const int tile = pick_tile(a.M, a.Co, cfg, ES == 2 && !extras);
+  const bool use128 = k128 && (cfg & 8) == 0 && !shallow && !((cfg & 7) == 0 && tile == 4);
+  if (tile == 4 && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
+  switch (tile) {
     case 1: return use128 ? launch_igemm<T, 128, 128, 128>(a, dgrad, st) : launch_igemm<T, 128, 128, 64>(a, dgrad, st);
     case 2: return use128 ? launch_igemm<T, 128, 64, 128>(a, dgrad, st) : launch_igemm<T, 128, 64, 64>(a, dgrad, st);
     case 3: return use128 ? launch_igemm<T, 64, 64, 128>(a, dgrad, st) : launch_igemm<T, 64, 64, 64>(a, dgrad, st);
@@ -993,8 +1008,8 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
 }
 
 // Block-tile rows used for a given cfg/shape (python sizes the stats partials with it).
-PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg) {
-  const int tile = pick_tile(M, Co, cfg);
+PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg, int dtype, int extras) {
+  const int tile = pick_tile(M, Co, cfg, dtype != PDA_F32 && !extras);
   return tile == 3 ? 64 : tile == 4 ? 256 : 128;
 }
 

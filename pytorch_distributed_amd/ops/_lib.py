@@ -28,7 +28,7 @@ c_d = ctypes.c_double
 c_ull = ctypes.c_ulonglong
 
 _SIGS = {
-    "pda_conv_igemm_bm": [c_i, c_i, c_i],
+    "pda_conv_igemm_bm": [c_i, c_i, c_i, c_i, c_i],
     "pda_conv_dgrad_stat_rows": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
     "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -79,7 +79,7 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     psum = psq = None
     slots = 0
     if stats:
-        bm = l.pda_conv_igemm_bm(M, K, cfg)
+        bm = l.pda_conv_igemm_bm(M, K, cfg, _lib.dt(x), int(res is not None))
         tiles_m = (M + bm - 1) // bm
         if stats_buf is not None and tiles_m > stats_buf.shape[1]:
             slots = stats_buf.shape[1]
