@@ -125,7 +125,7 @@ def test_wgrad_tiles_and_splits():
     dy = torch.randn(N, H, W, K, device=DEV).half()
     wr = torch.zeros(K, Cin, 3, 3, device=DEV, requires_grad=True)
     _ref_conv(x, wr, 1, 1).backward(dy.float())
-    for cfg in (1, 2, 3, 9, 10, 11):
+    for cfg in (1, 2, 3, 9, 10, 11, 12, 13):
         for nsplit in (0, 1, 3):
             for ws in (True, False):  # slab + reduce kernel vs float atomics
                 dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1), cfg=cfg, nsplit=nsplit, workspace=ws)
