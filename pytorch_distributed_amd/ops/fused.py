@@ -24,9 +24,10 @@ from . import _lib, conv as C, norm as Nm, pool as P
 
 
 # Smallest GEMM depth (Cout*R*S of the consuming conv's dgrad) for which the dgrad epilogue also takes the
-# producer's BatchNorm-backward sums: a deep GEMM hides the extra epilogue traffic behind the matrix work of
-# the other resident workgroup, a shallow one (1x1 convs off a narrow layer) is memory-bound already and
-# does better with the stand-alone streaming reduction.
+# producer's BatchNorm-backward sums.  Kernel by kernel the fusion only pays on deep GEMMs (a shallow 1x1
+# dgrad is memory-bound and its epilogue streams slower than the stand-alone reduction), but the whole
+# ResNet-50 step is fastest with every layer fused (threshold sweep in profiles/bench_1gpu_summary.txt),
+# hence the default 0.
 _SUMS_MIN_K = int(os.environ.get("PDA_FUSE_BN_SUMS_MIN_K", "0"))
 
 
@@ -97,7 +98,8 @@ class _ConvBnActFn(torch.autograd.Function):
             out_link.y = y if train_stats else None
             out_link.sums = None
         mask_src = out if (relu and not ctx.premasked and (residual is not None or not train_stats)) else None
-        ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd, scale, shift, gamma)
+        ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd,
+                              scale, shift, gamma)
         if passthrough:
             # second output = alias of the input: whatever consumes it (the block's identity branch)
             # sends its gradient back through THIS node, where the dgrad epilogue adds it for free
