@@ -5,11 +5,16 @@
 // /root/reference/2.distributed.py:213 and F.max_pool2d in
 // /root/reference/5.2.horovod_pytorch_mnist.py:46-47).
 #include "common.h"
+#include "pool_gather.h"
 
 template <typename T, int EPC>
 __global__ void __launch_bounds__(256)
 maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ idx, int N, int H,
-                   int W, int C, int Ho, int Wo, int k, int s, int p) {
+                   int W, int C, int Ho, int Wo, int k, int s, int p, const float* __restrict__ scale,
+                   const float* __restrict__ shift) {
+  // scale/shift given: x is a pre-normalisation tensor and the pooled value is relu(x*scale+shift), rounded
+  // to T exactly as a separate BatchNorm pass would have stored it (the ResNet stem: the 112x112 activation
+  // is never written)
   const int vpr = C / EPC;
   const long long total = (long long)N * Ho * Wo * vpr;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
@@ -19,10 +24,14 @@ maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* 
     const int wo = (int)(r % Wo); r /= Wo;
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
-    float best[EPC];
+    float best[EPC], sc[EPC], sf[EPC];
     unsigned char bi[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    if (scale) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc[e] = scale[cv * EPC + e]; sf[e] = shift[cv * EPC + e]; }
+    }
     for (int a = 0; a < k; ++a) {
       const int h = ho * s - p + a;
       if ((unsigned)h >= (unsigned)H) continue;
@@ -32,7 +41,8 @@ maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* 
         VecN<T, EPC> v = loadN<T, EPC>(x + (((long long)n * H + h) * W + w) * C + cv * EPC);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          const float f = ElemTraits<T>::to_f32(v.v[e]);
+          float f = ElemTraits<T>::to_f32(v.v[e]);
+          if (scale) f = ElemTraits<T>::to_f32(ElemTraits<T>::from_f32(fmaxf(f * sc[e] + sf[e], 0.f)));
           if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(a * k + b); }
         }
       }
@@ -56,44 +66,12 @@ maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__
                    int H, int W, int C, int Ho, int Wo, int k, int s, int p) {
   const int vpr = C / EPC;
   const long long total = (long long)N * H * W * vpr;
+  const PoolGeom g = {H, W, Ho, Wo, k, s, p};
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % vpr);
-    long long r = i / vpr;
-    const int w = (int)(r % W); r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
     float acc[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    // windows ho with ho*s - p <= h <= ho*s - p + k - 1
-    int ho_lo = (h + p - k + 1 + s - 1);
-    ho_lo = ho_lo < 0 ? 0 : ho_lo / s;
-    int ho_hi = (h + p) / s;
-    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
-    int wo_lo = (w + p - k + 1 + s - 1);
-    wo_lo = wo_lo < 0 ? 0 : wo_lo / s;
-    int wo_hi = (w + p) / s;
-    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
-    for (int ho = ho_lo; ho <= ho_hi; ++ho)
-      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        const int a = h - (ho * s - p), b = w - (wo * s - p);
-        const unsigned char me = (unsigned char)(a * k + b);
-        const long long o = ((((long long)n * Ho + ho) * Wo + wo) * vpr + cv) * EPC;
-        VecN<T, EPC> g = loadN<T, EPC>(dout + o);
-        unsigned char ib[EPC];
-        if constexpr (EPC == 8) {
-          *reinterpret_cast<u32x2*>(ib) = *reinterpret_cast<const u32x2*>(idx + o);
-        } else if constexpr (EPC == 4) {
-          *reinterpret_cast<unsigned int*>(ib) = *reinterpret_cast<const unsigned int*>(idx + o);
-        } else {
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) ib[e] = idx[o + e];
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if (ib[e] == me) acc[e] += ElemTraits<T>::to_f32(g.v[e]);
-      }
+    pool_grad_gather<T, EPC>(dout, idx, g, i / vpr, cv, vpr, acc);
     VecN<T, EPC> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e]);
@@ -161,7 +139,8 @@ static inline int ew_blocks(long long n) {
   }
 
 PDA_EXPORT int pda_maxpool_fwd(int dtype, const void* x, void* out, unsigned char* idx, int N, int H, int W, int C,
-                               int Ho, int Wo, int k, int s, int p, hipStream_t st) {
+                               int Ho, int Wo, int k, int s, int p, const float* scale, const float* shift,
+                               hipStream_t st) {
   int epc = dtype == PDA_F32 ? 4 : 8;
   const bool vec = (C % epc) == 0;
   if (!vec) epc = 1;
@@ -169,7 +148,7 @@ PDA_EXPORT int pda_maxpool_fwd(int dtype, const void* x, void* out, unsigned cha
   const long long total = (long long)N * Ho * Wo * (C / epc);
   if (total == 0) return 0;
   PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_fwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
-                                           (const T*)x, (T*)out, idx, N, H, W, C, Ho, Wo, k, s, p));
+                                           (const T*)x, (T*)out, idx, N, H, W, C, Ho, Wo, k, s, p, scale, shift));
   return pda_check_launch();
 }
 

@@ -50,7 +50,7 @@ _SIGS = {
     "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_i, c_i, c_p],
     "pda_bn_bwd_coefs": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p],
     "pda_bn_bwd_apply": [c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_p],
-    "pda_maxpool_fwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pda_maxpool_fwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "pda_maxpool_bwd": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_gap_fwd": [c_i, c_p, c_p, c_i, c_i, c_i, c_p],
     "pda_gap_bwd": [c_i, c_p, c_p, c_i, c_i, c_i, c_p],

@@ -293,12 +293,17 @@ class _StemFn(torch.autograd.Function):
             if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
                 mean_, invstd = Nm.eval_moments(st)
             count = float(y.numel() // K)
-        act = Nm.apply(y, scale, shift, None, True)
-        if pool is not None:
-            out, idx = P.maxpool_fwd_gpu(act, *pool)
+        if pool is not None and train_stats:
+            # normalise + ReLU + pool in one pass: the full-resolution activation is never written (the
+            # backward needs y and the arg-max bytes only).  The backward keeps the materialised max-pool
+            # gradient: gathering it through the arg-max bytes inside both BatchNorm-backward passes was
+            # measured slower (1.23 vs 1.01 ms at batch 400) than writing it once.
+            act = None
+            out, idx = P.maxpool_fwd_gpu(y, *pool, scale=scale, shift=shift)
         else:
-            out, idx = act, None
-        ctx.cfg = (stride, pad, geom, count, st.group, pool, act.shape, train_stats, weight.shape)
+            act = Nm.apply(y, scale, shift, None, True)
+            out, idx = P.maxpool_fwd_gpu(act, *pool) if pool is not None else (act, None)
+        ctx.cfg = (stride, pad, geom, count, st.group, pool, tuple(y.shape), train_stats, weight.shape)
         ctx.beta = beta
         ctx.save_for_backward(xp, y if (train_stats or mean_ is not None) else None, idx, mean_, invstd, scale, shift, gamma,
                               act if not train_stats else None)

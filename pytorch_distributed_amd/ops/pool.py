@@ -12,14 +12,16 @@ from . import _lib
 from .conv import out_size
 
 
-def maxpool_fwd_gpu(x: torch.Tensor, k: int, s: int, p: int):
+def maxpool_fwd_gpu(x: torch.Tensor, k: int, s: int, p: int, scale=None, shift=None):
+    """-> (pooled, arg-max bytes).  With ``scale``/``shift`` (fp32 [C]) the pooled quantity is
+    ``relu(x*scale+shift)``: BatchNorm apply + ReLU + pool in one pass, without the full-size activation."""
     l = _lib.lib()
     N, H, W, Cc = x.shape
     Ho, Wo = out_size(H, k, s, p), out_size(W, k, s, p)
     out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
     idx = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.uint8)
     _lib.check(l.pda_maxpool_fwd(_lib.dt(x), x.data_ptr(), out.data_ptr(), idx.data_ptr(), N, H, W, Cc, Ho, Wo, k, s,
-                                 p, _lib.stream()), "pda_maxpool_fwd")
+                                 p, _lib.ptr(scale), _lib.ptr(shift), _lib.stream()), "pda_maxpool_fwd")
     return out, idx
 
 
