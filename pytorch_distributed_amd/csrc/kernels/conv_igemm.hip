@@ -959,8 +959,8 @@ static const long long kBigTiles = [] {
 
 // cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (each of the 2x2 waves owns
 // 128x64 outputs); bit 3 forces 64-byte K rows.
-// big_ok: 16-bit plain kernel.  The 128x128 tile is bound by LDS traffic (every wave re-reads a 64-row A
-// and a 64-row B slice per 16 MFMAs); a 128x64 wave tile moves 25 % fewer LDS bytes per MFMA and measured
+// big_ok: 16-bit plain kernel.  With the 128x128 tile every wave re-reads a 64-row A and a 64-row B slice
+// per 16 MFMAs and waits on those reads; a 128x64 wave tile moves 25 % fewer LDS bytes per MFMA and measured
 // 5-10 % faster in isolation on the deep layers at 28x28 and 14x14 - as long as there are enough tiles to fill the chip
 // twice, and with 32-deep K steps (the 64-deep version needs 96 KB of LDS: one workgroup per CU).
 static int pick_tile(int M, int Co, int cfg, bool big_ok = false) {
