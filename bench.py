@@ -48,6 +48,9 @@ def parse():
                     help="record the step into a hipGraph after warm-up and replay it (single GPU, native engine)")
     ap.add_argument("--native-comm", action="store_true",
                     help="gradient all-reduce through this package's own RCCL communicator instead of torch.distributed")
+    ap.add_argument("--autotune", action=argparse.BooleanOptionalAction, default=True,
+                    help="backends.benchmark: time the candidate conv tile configurations per layer shape during "
+                         "warm-up (the reference sets cudnn.benchmark = True, /root/reference/2.distributed.py:122)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
                          "all-reduce path on a single GPU)")
@@ -80,7 +83,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from pytorch_distributed_amd import models, ops, amp
+    from pytorch_distributed_amd import models, ops, amp, backends
+    backends.benchmark = bool(args.autotune) and args.warmup > 0   # the tuning runs belong to the warm-up steps
     from pytorch_distributed_amd.optim import FusedSGD
 
     torch.manual_seed(1234 + rank)
@@ -174,7 +178,7 @@ def main():
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
                        "device": "cpu (rehearsal, not a result)" if on_cpu else torch.cuda.get_device_name(dev),
-                       "weights": "random-init", "final_loss": round(final_loss, 4), "hip_graph": graphed,
+                       "weights": "random-init", "conv_autotune": backends.benchmark if args.engine == "native" else None, "final_loss": round(final_loss, 4), "hip_graph": graphed,
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
         print(json.dumps(out), flush=True)

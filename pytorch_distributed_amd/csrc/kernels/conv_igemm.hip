@@ -605,6 +605,8 @@ struct WgradArgs {
   float* slab;        // optional [nsplit][Co][Ktot] scratch: split-K partials stored, not atomically added
   long long slab_bytes;
   int r_lo, r_hi, s_lo, s_hi;  // taps outside this window only ever multiply padding: their dW stays zero
+  int det;                     // host side only: run-to-run reproducible split-K reduction (no float atomics
+                               // racing on one element): slabs + ordered reduce, or a single split
 };
 
 template <typename T> struct TrRead;
@@ -1090,6 +1092,7 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
   }
+  if (a.det && nsplit > 32) nsplit = 32;  // the slab reduction takes at most 32 splits
   int pps = (a.M + nsplit - 1) / nsplit;
   pps = ((pps + BKP - 1) / BKP) * BKP;
   nsplit = (a.M + pps - 1) / pps;
@@ -1102,6 +1105,10 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   const bool slabs = nsplit > 1 && nsplit <= 32 && a.slab != nullptr && (long long)nsplit * n * 4 <= a.slab_bytes &&
                      (n % 4) == 0 && (((uintptr_t)a.dw | (uintptr_t)a.slab) & 15) == 0;
   if (!slabs) a.slab = nullptr;
+  if (a.det && !slabs && nsplit > 1) {  // no workspace: one split per tile, each dW element gets one add
+    nsplit = 1;
+    a.pix_per_split = ((a.M + BKP - 1) / BKP) * BKP;
+  }
   hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP>), dim3(tiles, nsplit), dim3(256), 0, st, a);
   if (slabs) {
     const long long n4 = n / 4;
@@ -1123,6 +1130,7 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.R = R; a.S = S;
   a.stride_h = stride_h; a.stride_w = stride_w; a.pad_h = pad_h; a.pad_w = pad_w;
   a.M = N * Ho * Wo; a.Ktot = R * S * Ci; a.pix_per_split = 0;
+  a.det = (cfg & 32) != 0;  // cfg bit 5
   if (a.M <= 0) return 0;
   {
     const long long rl = (long long)pad_h - (long long)(Ho - 1) * stride_h, rh = (long long)Hi - 1 + pad_h;

@@ -244,7 +244,11 @@ def fit(args, model, optimizer, device, train_set, val_set, per_rank_batch: int,
         zero_grad: Optional[Callable] = None, csv_path: Optional[str] = None, save_prefix_arch: bool = True,
         is_chief: Optional[bool] = None, samplers: Optional[tuple] = None):
     from .nn import CrossEntropyLoss
+    from . import backends
     criterion = CrossEntropyLoss()
+    # the reference's `cudnn.benchmark = True` (/root/reference/2.distributed.py:122): per-shape selection of the
+    # conv tile configuration by timing, during the first iteration
+    backends.benchmark = device.type == "cuda"
     if samplers is not None:
         train_sampler, val_sampler = samplers
     elif distributed:

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from .. import backends
 
 _PARAM_GENERATION = 0  # bumped by our optimizers, which update weights behind autograd's back
 # BatchNorm statistic partials: one row per tile (default), or PDA_STAT_SLOTS=1 = a few float-atomic
@@ -36,6 +37,41 @@ def bump_param_generation() -> None:
 
 def param_generation() -> int:
     return _PARAM_GENERATION
+
+
+_TUNED: dict = {}
+_FPROP_CFGS = (0, 1, 2, 9, 10, 12)   # 0 = heuristic; 128x128, 128x64, the same with 32-deep K steps, 256x128
+_DGRAD_EX_CFGS = (0, 1, 2, 9, 10)    # the fused-epilogue kernels have no 256x128 tile
+_WGRAD_CFGS = (0, 1, 9, 12)
+
+
+def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
+    """``backends.benchmark``: the fastest of ``cands`` for this (op, shape), measured once with device
+    events on the caller's operands.  A candidate has to beat the heuristic (``cands[0]``) by 3 % to
+    replace it, so timing noise does not churn the choice."""
+    k = (kind,) + key
+    hit = _TUNED.get(k)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        return cands[0]
+    times = []
+    for c in cands:
+        if run(c) is None:          # configuration not available for this shape
+            times.append(float("inf"))
+            continue
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            run(c)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    best = min(range(len(cands)), key=lambda i: times[i])
+    choice = cands[best] if times[best] < 0.97 * times[0] else cands[0]
+    _TUNED[k] = choice
+    return choice
 
 
 def out_size(i: int, k: int, s: int, p: int) -> int:
@@ -75,6 +111,11 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     else:
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
     M = N * Ho * Wo
+    if cfg == 0 and backends.benchmark and geom is None:
+        cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats),
+                         _FPROP_CFGS if res is None else _DGRAD_EX_CFGS,
+                         lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None))
+    cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
     y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
     psum = psq = None
     slots = 0
@@ -115,6 +156,14 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     N, Ho, Wo, K = dy.shape
     C, R, S = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[2]
     Hi, Wi = in_hw
+    if cfg == 0 and backends.benchmark:
+        extras = res is not None or mask is not None or bn_input is not None
+        cfg = _tuned_cfg("dgrad", (dy.dtype, N, Ho, Wo, K, C, R, S, Hi, Wi, tuple(stride), tuple(pad), res is not None,
+                                   mask is not None, bn_input is not None, bn_scale is not None, bn_sums),
+                         _DGRAD_EX_CFGS if extras else _FPROP_CFGS,
+                         lambda c: dgrad_gpu(dy, w_crsk, in_hw, stride, pad, res, c or 1 << 30, mask, bn_input, bn_scale,
+                                             bn_shift, bn_sums))
+    cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
     for name, t in (("res", res), ("mask", mask), ("bn_input", bn_input)):
         if t is not None and (t.shape != dx.shape or t.dtype != dx.dtype or not t.is_contiguous()):
@@ -178,6 +227,13 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
         sn, sh, sw = Hi * Wi * Ci, Wi * Ci, Ci
     else:
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
+    if cfg == 0 and nsplit == 0 and backends.benchmark and geom is None:
+        cfg = _tuned_cfg("wgrad", (dy.dtype, N, Hi, Wi, Ci, Ho, Wo, K, R, S, tuple(stride), tuple(pad), workspace,
+                                   backends.deterministic), _WGRAD_CFGS,
+                         lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, None, None, workspace))
+    cfg &= (1 << 30) - 1
+    if backends.deterministic:
+        cfg |= 32
     dw = out if out is not None else torch.zeros((K, R, S, Ci), device=dy.device, dtype=torch.float32)
     ws = _wgrad_workspace(dy.device) if workspace else None
     rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,

@@ -25,14 +25,17 @@ def adjust_learning_rate(optimizer, epoch: int, base_lr, decay_every: int = 30, 
 
 def seed_everything(seed: Optional[int], deterministic: bool = True, warn: bool = True) -> None:
     """``--seed`` handling of the reference (/root/reference/2.distributed.py:82-90): seed python and
-    torch RNGs and emit the same slowdown warning (there is no cuDNN switch to flip here: the
-    HIP kernels of this package are deterministic except for float-atomic wgrad accumulation)."""
+    torch RNGs, switch the kernels to their run-to-run reproducible forms (``backends.deterministic``: the
+    wgrad split-K reduction stops using float atomics) and emit the same slowdown warning."""
     if seed is None:
         return
     random.seed(seed)
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+    if deterministic:
+        from .. import backends
+        backends.deterministic = True   # the counterpart of cudnn.deterministic = True
     if warn:
         warnings.warn("You have chosen to seed training. This will turn on deterministic settings, "
                       "which can slow down your training considerably! You may see unexpected behavior "

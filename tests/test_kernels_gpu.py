@@ -631,6 +631,39 @@ def test_two_fused_layers_many_tiles():
     assert rel_err(b1.running_var, rb1.running_var) < 1e-4
 
 
+def test_backends_benchmark_and_deterministic():
+    """backends.benchmark picks a configuration per shape without changing results; backends.deterministic
+    makes wgrad bit-reproducible on a shape whose default split-K reduction uses float atomics."""
+    from pytorch_distributed_amd import backends
+    torch.manual_seed(41)
+    N, H, Cin, K = 8, 28, 64, 64          # 64-wide: many pixel splits of a small dW -> atomics by default
+    x = torch.randn(N, H, H, Cin, device=DEV).half()
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 24).half()
+    dy = torch.randn(N, H, H, K, device=DEV).half()
+    wt = C.krsc_to_crsk(w, torch.float16)
+    ref_y = C.fprop_gpu(x, w, (1, 1), (1, 1))
+    ref_dx = C.dgrad_gpu(dy, wt, (H, H), (1, 1), (1, 1))
+    ref_dw = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1))
+    old = (backends.benchmark, backends.deterministic)
+    try:
+        backends.benchmark = True
+        C._TUNED.clear()
+        for _ in range(2):  # first call tunes, second uses the cached choice
+            assert rel_err(C.fprop_gpu(x, w, (1, 1), (1, 1)), ref_y) < 2e-3
+            assert rel_err(C.dgrad_gpu(dy, wt, (H, H), (1, 1), (1, 1)), ref_dx) < 2e-3
+            assert rel_err(C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1)), ref_dw) < 2e-3
+        assert {k[0] for k in C._TUNED} == {"fprop", "dgrad", "wgrad"}
+        backends.benchmark = False
+        backends.deterministic = True
+        a = C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1))
+        for _ in range(3):
+            assert torch.equal(C.wgrad_gpu(dy, x, 3, 3, (1, 1), (1, 1)), a)
+        assert rel_err(a, ref_dw) < 2e-3
+    finally:
+        backends.benchmark, backends.deterministic = old
+        C._TUNED.clear()
+
+
 def test_mnist_net_gpu_matches_cpu():
     torch.manual_seed(13)
     net = models.Net().eval()
