@@ -40,9 +40,10 @@ def param_generation() -> int:
 
 
 _TUNED: dict = {}
-_FPROP_CFGS = (0, 1, 2, 9, 10, 12)   # 0 = heuristic; 128x128, 128x64, the same with 32-deep K steps, 256x128
-_DGRAD_EX_CFGS = (0, 1, 2, 9, 10)    # the fused-epilogue kernels have no 256x128 tile
-_WGRAD_CFGS = (0, 1, 9, 12)
+# 0 = heuristic; 1/2/3 = 128x128, 128x64, 64x64 tiles; +8 = 32-deep K steps; 12 = 256x128 (128x64 per wave)
+_FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)
+_DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11)       # the fused-epilogue kernels have no 256x128 tile
+_WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
 
 
 def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
