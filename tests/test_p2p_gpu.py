@@ -53,7 +53,7 @@ def _start_ranks(worker, world):
     outs = []
     try:
         for p in procs:
-            o, _ = p.communicate(timeout=240)
+            o, _ = p.communicate(timeout=100)
             outs.append(o)
     finally:
         for p in procs:
@@ -71,3 +71,8 @@ def test_syncbn_statistics_over_p2p():
     """SyncBatchNorm forward/backward == BatchNorm over the concatenated batch, with the [2, C] statistics
     reduced by the peer-memory kernel (PDA_P2P_SMALL=1) under a gloo process group."""
     _run_ranks(os.path.join(ROOT, "tests", "workers", "p2p_syncbn_worker.py"), 2)
+
+
+def test_syncbn_resnet_two_ranks_matches_full_batch():
+    """Fused conv+SyncBatchNorm ResNet-18 on two ranks == plain BatchNorm on the concatenated batch."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "syncbn_resnet_worker.py"), 2)
