@@ -155,3 +155,80 @@ class P2PAllReduce:
         if self._own:
             self._l.pda_p2p_free(self._own)
         self._own = None
+
+
+class _Done:
+    def wait(self):
+        return True
+
+    def is_completed(self):
+        return True
+
+
+class P2PCollectives:
+    """The collectives interface ``DistributedDataParallel(comm=...)`` expects, on top of
+    :class:`P2PAllReduce`: floating-point device tensors are reduced in chunks of ``max_elems`` by the
+    peer-memory kernel (in stream order, staged through fp32 for 16-bit tensors); everything else (integer
+    tensors, CPU tensors, min/max/prod) is staged through the host over ``group``.  One workgroup per rank
+    moves the data, so this is a correctness backend for single-node jobs without RCCL (and what lets the
+    multi-rank DDP path be tested with several processes on one GPU), not a bandwidth path."""
+
+    def __init__(self, rank: int, world_size: int, store=None, group=None, device=None, max_elems: int = 1 << 20,
+                 key: str = "pda/p2pc", timeout_ms: int = 5000):
+        import torch.distributed as dist
+        self._dist, self.group = dist, group
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.backend = "p2p"
+        self._ar = P2PAllReduce(rank, world_size, store=store, device=device, max_elems=max_elems, key=key,
+                                timeout_ms=timeout_ms, group=group)
+
+    def _host(self, t: torch.Tensor, fn) -> None:
+        c = t.detach().cpu()
+        fn(c)
+        t.copy_(c)
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
+        if t.is_cuda and t.is_floating_point() and op in ("sum", "avg") and t.is_contiguous():
+            flat = t.view(-1)
+            n, m = flat.numel(), self._ar.max_elems
+            for off in range(0, n, m):
+                piece = flat[off:off + m]
+                if piece.dtype == torch.float32:
+                    self._ar.all_reduce(piece, op)
+                else:
+                    f = piece.float()
+                    self._ar.all_reduce(f, op)
+                    piece.copy_(f)
+        else:
+            d = self._dist
+            rop = {"sum": d.ReduceOp.SUM, "avg": d.ReduceOp.SUM, "prod": d.ReduceOp.PRODUCT, "min": d.ReduceOp.MIN,
+                   "max": d.ReduceOp.MAX}[op]
+
+            def run(c):
+                d.all_reduce(c, op=rop, group=self.group)
+                if op == "avg":
+                    c /= self.world_size
+            self._host(t, run)
+        return _Done() if async_op else None
+
+    def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
+        if t.is_cuda and t.is_floating_point() and t.is_contiguous():
+            if self.rank != src:
+                t.zero_()
+            self.all_reduce(t, "sum")   # everybody but src contributes zeros
+        else:
+            self._host(t, lambda c: self._dist.broadcast(c, src=src, group=self.group))
+        return _Done() if async_op else None
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    @property
+    def device_collectives(self) -> bool:
+        return True
+
+    def check(self) -> None:
+        self._ar.check()
+
+    def close(self) -> None:
+        self._ar.close()

@@ -76,3 +76,9 @@ def test_syncbn_statistics_over_p2p():
 def test_syncbn_resnet_two_ranks_matches_full_batch():
     """Fused conv+SyncBatchNorm ResNet-18 on two ranks == plain BatchNorm on the concatenated batch."""
     _run_ranks(os.path.join(ROOT, "tests", "workers", "syncbn_resnet_worker.py"), 2)
+
+
+def test_ddp_two_ranks_on_one_gpu_matches_full_batch():
+    """The device-side multi-rank reducer path (two processes, peer-memory collectives): DDP + SyncBatchNorm +
+    FusedSGD for two steps == one process on the concatenated batch."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), 2)
