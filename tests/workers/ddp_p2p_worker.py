@@ -45,6 +45,7 @@ def main():
     torch.manual_seed(11)
     ok = True
     msgs = []
+    w0 = [q.detach().clone() for q in ref.parameters()]   # both models start here (DDP broadcast rank 0's copy)
     for step in range(2):
         x = torch.randn(world * per, 3, 32, 32, device=dev)
         t = torch.randint(0, 10, (world * per,), device=dev)
@@ -62,8 +63,13 @@ def main():
             e = ((p - q).norm() / (q.norm() + 1e-12)).item()
             if e > worst:
                 worst, wk = e, k
-        msgs.append(f"step {step}: worst weight diff {worst:.2e} ({wk})")
-        ok = ok and worst < 1e-3
+        # the UPDATE is what the gradients produced: compare it as one vector (weights barely move in two
+        # steps, so a weight comparison alone would not notice a wrong reduction)
+        du = torch.cat([(p.detach() - a).flatten() for p, a in zip(net.parameters(), w0)])
+        dr = torch.cat([(q.detach() - a).flatten() for q, a in zip(ref.parameters(), w0)])
+        upd = ((du - dr).norm() / dr.norm()).item()
+        msgs.append(f"step {step}: worst weight diff {worst:.2e} ({wk}), update rel err {upd:.2e}")
+        ok = ok and worst < 1e-3 and upd < 2e-2
     coll.check()
     nb = len(ddp.bucket_summary())
     print(f"rank {rank}: {'OK' if ok else 'FAILED'} buckets {nb}; " + "; ".join(msgs), flush=True)
