@@ -121,6 +121,7 @@ class _State:
         self.side_stream = None
         self.torch_group_ready = False
         self.multi_host = False
+        self.dev_coll = None   # device collectives override (PDA_HVD_DEVICE_COMM=p2p)
 
 
 _S = _State()
@@ -156,6 +157,12 @@ def init(comm=None, process_sets=None) -> None:
     _S.lib = _runtime.lib()
     _S.shm = ShmCommunicator(PrefixStore("hvd", base), info.rank, info.world_size, name="engine",
                              slot_bytes=int(os.environ.get("PDA_HVD_SHM_SLOT_BYTES", str(8 << 20))))
+    if os.environ.get("PDA_HVD_DEVICE_COMM", "") == "p2p" and torch.cuda.is_available():
+        # device tensors through the peer-memory backend instead of RCCL (single node; also what lets the
+        # device path run with several ranks on one GPU, where RCCL refuses duplicate devices)
+        from ..comm.p2p import P2PCollectives
+        dev = torch.device("cuda", int(os.environ.get("PDA_HVD_P2P_DEVICE", str(info.local_rank))))
+        _S.dev_coll = P2PCollectives(info.rank, info.world_size, store=PrefixStore("hvdp2p", base), device=dev)
     _S.exec_cb = _EXEC_T(_device_executor)
     fusion = int(float(os.environ.get("HOROVOD_FUSION_THRESHOLD", str(64 << 20))))
     cycle = float(os.environ.get("HOROVOD_CYCLE_TIME", "1.0"))
@@ -171,6 +178,9 @@ def shutdown() -> None:
         _S.lib.pda_hvd_shutdown(_S.engine)
         _S.lib.pda_hvd_destroy(_S.engine)
         _S.engine = None
+    if _S.dev_coll is not None:
+        _S.dev_coll.close()
+        _S.dev_coll = None
     if _S.shm is not None:
         _S.shm.close()
         _S.shm = None
@@ -297,21 +307,32 @@ def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
             for p in ps:
                 if p.event is not None:
                     _S.side_stream.wait_event(p.event)
+            coll = _S.dev_coll
             if kind == 1:
                 for p in ps:
-                    dist.broadcast(p.wire, src=root)
+                    if coll is not None:
+                        coll.broadcast(p.wire, root)
+                    else:
+                        dist.broadcast(p.wire, src=root)
             else:
                 red = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.PRODUCT, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX,
                        4: dist.ReduceOp.SUM}[op_code]
+                rname = {0: "sum", 1: "prod", 2: "min", 3: "max", 4: "sum"}[op_code]
+
+                def all_reduce(t):
+                    if coll is not None:
+                        coll.all_reduce(t, rname)
+                    else:
+                        dist.all_reduce(t, op=red)
                 scale = (1.0 / _S.info.world_size) if op_code == 4 else 1.0
                 if n == 1:
-                    dist.all_reduce(ps[0].wire, op=red)
+                    all_reduce(ps[0].wire)
                     if scale != 1.0:
                         ps[0].wire.mul_(scale)
                 else:
                     wires = [p.wire.view(-1) for p in ps]
                     flat = mt.flatten(wires)
-                    dist.all_reduce(flat, op=red)
+                    all_reduce(flat)
                     views, off = [], 0
                     for w in wires:
                         views.append(flat[off:off + w.numel()])

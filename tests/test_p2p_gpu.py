@@ -82,3 +82,8 @@ def test_ddp_two_ranks_on_one_gpu_matches_full_batch():
     """The device-side multi-rank reducer path (two processes, peer-memory collectives): DDP + SyncBatchNorm +
     FusedSGD for two steps == one process on the concatenated batch."""
     _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), 2)
+
+
+def test_hvd_optimizer_two_ranks_on_one_gpu():
+    """hvd.DistributedOptimizer over device tensors, engine collectives through the peer-memory backend."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), 2)
