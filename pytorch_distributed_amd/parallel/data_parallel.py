@@ -141,10 +141,22 @@ def reduce_add_coalesced(per_device: Sequence[Sequence[torch.Tensor]], target) -
     target = _dev(target)
     n = len(per_device[0])
     first = [t if t.device == target else t.to(target) for t in per_device[0]]
-    acc = mt.flatten([t.reshape(-1) if t.is_contiguous() else _physical_flat(t) for t in first])
+    # a gradient that is a strided slice of something larger (the stem's dW is cut out of a padded buffer)
+    # has no physical order to add in: bring it to plain contiguous layout first
+    first = [t if _is_dense(t) else t.contiguous() for t in first]
+
+    def flat_like(t, ref):
+        """1-D view/copy of t whose element order is ref's PHYSICAL order (so flats can be added blindly)."""
+        if _is_dense(t) and t.stride() == ref.stride():
+            return t.reshape(-1) if t.is_contiguous() else _physical_flat(t)
+        same = torch.empty_strided(ref.shape, ref.stride(), dtype=t.dtype, device=t.device)
+        same.copy_(t)
+        return _physical_flat(same)
+
+    acc = mt.flatten([flat_like(t, t) for t in first])
     flats = []
     for lst in per_device[1:]:
-        flat = mt.flatten([t.reshape(-1) if t.is_contiguous() else _physical_flat(t) for t in lst])
+        flat = mt.flatten([flat_like(t, r) for t, r in zip(lst, first)])
         flats.append(flat.to(target, non_blocking=True))   # one peer copy per replica (xGMI)
     if flats and acc.is_cuda and acc.dtype in (torch.float32, torch.float16, torch.bfloat16):
         from ..ops.elementwise import add_n

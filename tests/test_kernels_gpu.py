@@ -664,6 +664,31 @@ def test_backends_benchmark_and_deterministic():
         C._TUNED.clear()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_data_parallel_two_replicas_on_one_gpu(dtype):
+    """Single-process DataParallel with both replicas on the one GPU: scatter, replicate (broadcast_coalesced),
+    thread-per-replica apply, gather, and the reduce-add backward through the N-way add kernel, against the
+    module on the whole batch (eval-mode BatchNorm: statistics are per replica under DataParallel)."""
+    from pytorch_distributed_amd.parallel.data_parallel import DataParallel
+    torch.manual_seed(51)
+    m = models.resnet18(num_classes=10).to(DEV).set_compute_dtype(dtype).eval()
+    dp = DataParallel(m, device_ids=[0, 0], output_device=0)
+    x = torch.randn(6, 3, 32, 32, device=DEV)
+    t = torch.randint(0, 10, (6,), device=DEV)
+    out = dp(x)
+    ref = m(x)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert out.shape == (6, 10) and rel_err(out, ref) < tol
+    (ops.cross_entropy(out, t) * 64.0).backward()
+    g_dp = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    (ops.cross_entropy(m(x), t) * 64.0).backward()
+    flat_dp = torch.cat([g.float().flatten() for g in g_dp])
+    flat = torch.cat([p.grad.float().flatten() for p in m.parameters()])
+    assert rel_err(flat_dp, flat) < (1e-4 if dtype == torch.float32 else 5e-2)
+    assert list(dp.state_dict().keys())[0].startswith("module.")
+
+
 def test_mnist_net_gpu_matches_cpu():
     torch.manual_seed(13)
     net = models.Net().eval()
