@@ -62,7 +62,7 @@ def _start_ranks(worker, world):
     return procs, outs
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_allreduce_processes_on_one_gpu(world):
     _run_ranks(WORKER, world)
 
