@@ -78,10 +78,11 @@ def test_syncbn_resnet_two_ranks_matches_full_batch():
     _run_ranks(os.path.join(ROOT, "tests", "workers", "syncbn_resnet_worker.py"), 2)
 
 
-def test_ddp_two_ranks_on_one_gpu_matches_full_batch():
-    """The device-side multi-rank reducer path (two processes, peer-memory collectives): DDP + SyncBatchNorm +
-    FusedSGD for two steps == one process on the concatenated batch."""
-    _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), 2)
+@pytest.mark.parametrize("world", [2, 8])
+def test_ddp_ranks_on_one_gpu_match_full_batch(world):
+    """The device-side multi-rank reducer path (2 and 8 processes, peer-memory collectives): DDP +
+    SyncBatchNorm + FusedSGD for two steps == one process on the concatenated batch."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), world)
 
 
 def test_hvd_optimizer_two_ranks_on_one_gpu():
