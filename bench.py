@@ -188,4 +188,12 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    try:
+        rc = main()
+    except Exception as e:  # noqa: BLE001 - a failed run must still say why, in the one place the driver reads
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"error": f"{type(e).__name__}: {e}"[:500]}), flush=True)
+        rc = 1
+    sys.exit(rc)
