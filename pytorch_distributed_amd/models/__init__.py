@@ -8,11 +8,20 @@ import os
 
 import torch
 
-from .resnet import ResNet, BasicBlock, Bottleneck, resnet18, resnet34, resnet50, resnet101, resnet152
+from .resnet import (ResNet, BasicBlock, Bottleneck, resnet18, resnet34, resnet50, resnet101, resnet152,
+                     wide_resnet50_2, wide_resnet101_2)
+from .vgg import VGG, AlexNet, alexnet, vgg11, vgg11_bn, vgg13, vgg13_bn, vgg16, vgg16_bn, vgg19, vgg19_bn
+from .squeezenet import SqueezeNet, squeezenet1_0, squeezenet1_1
+from .densenet import DenseNet, densenet121, densenet161, densenet169, densenet201
 from .mnist import Net, mnist_net
 from .reference import torch_resnet, TorchResNet
 
-model_names = sorted(["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "mnist_net"])
+# Families built from dense convolutions.  torchvision's grouped / depthwise families (resnext*,
+# mobilenet*, shufflenet*, mnasnet*) and the multi-branch Inception / GoogLeNet are not provided.
+model_names = sorted(["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "wide_resnet50_2",
+                      "wide_resnet101_2", "alexnet", "vgg11", "vgg11_bn", "vgg13", "vgg13_bn", "vgg16", "vgg16_bn",
+                      "vgg19", "vgg19_bn", "squeezenet1_0", "squeezenet1_1", "densenet121", "densenet161",
+                      "densenet169", "densenet201", "mnist_net"])
 
 
 def get_model(arch: str, pretrained: bool = False, **kw):
@@ -34,5 +43,5 @@ def load_pretrained(model, arch: str) -> None:
     model.load_state_dict(sd.get("state_dict", sd))
 
 
-__all__ = ["ResNet", "BasicBlock", "Bottleneck", "resnet18", "resnet34", "resnet50", "resnet101", "resnet152",
+__all__ = ["ResNet", "BasicBlock", "Bottleneck", "VGG", "AlexNet", "SqueezeNet", "DenseNet", *model_names,
            "Net", "mnist_net", "torch_resnet", "TorchResNet", "model_names", "get_model", "load_pretrained"]

@@ -1,5 +1,5 @@
-"""ResNet-18/34/50/101/152 (torchvision v1.5 topology: stride on the 3x3 of a
-bottleneck) built on the fused NHWC ops.
+"""ResNet-18/34/50/101/152 and Wide-ResNet-50-2/101-2 (torchvision v1.5 topology: stride on
+the 3x3 of a bottleneck) built on the fused NHWC ops.
 
 ``state_dict()`` keys, shapes and dtypes are those of torchvision's ResNet
 (``conv1.weight``, ``layer1.0.bn1.running_mean``, ``layer2.0.downsample.0.weight``,
@@ -60,8 +60,10 @@ def _links(block, n_inner: int):
 class BasicBlock(tnn.Module):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None):
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64):
         super().__init__()
+        if base_width != 64:
+            raise ValueError("BasicBlock only supports base_width=64")
         self.conv1 = _conv3x3(inplanes, planes, stride)
         self.bn1 = pnn.BatchNorm2d(planes)
         self.relu = pnn.ReLU()
@@ -87,13 +89,14 @@ class BasicBlock(tnn.Module):
 class Bottleneck(tnn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None):
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64):
         super().__init__()
-        self.conv1 = _conv1x1(inplanes, planes)
-        self.bn1 = pnn.BatchNorm2d(planes)
-        self.conv2 = _conv3x3(planes, planes, stride)
-        self.bn2 = pnn.BatchNorm2d(planes)
-        self.conv3 = _conv1x1(planes, planes * self.expansion)
+        width = planes * base_width // 64     # wide_resnet*_2: twice the inner (3x3) width, same block output
+        self.conv1 = _conv1x1(inplanes, width)
+        self.bn1 = pnn.BatchNorm2d(width)
+        self.conv2 = _conv3x3(width, width, stride)
+        self.bn2 = pnn.BatchNorm2d(width)
+        self.conv3 = _conv1x1(width, planes * self.expansion)
         self.bn3 = pnn.BatchNorm2d(planes * self.expansion)
         self.relu = pnn.ReLU()
         self.downsample = downsample
@@ -115,9 +118,11 @@ class Bottleneck(tnn.Module):
 
 class ResNet(tnn.Module):
     def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], num_classes: int = 1000,
-                 zero_init_residual: bool = False, input_mean=None, input_std=None, input_scale: float = 1.0):
+                 zero_init_residual: bool = False, input_mean=None, input_std=None, input_scale: float = 1.0,
+                 width_per_group: int = 64):
         super().__init__()
         self.inplanes = 64
+        self.base_width = width_per_group
         self.conv1 = pnn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = pnn.BatchNorm2d(64)
         self.relu = pnn.ReLU()
@@ -181,10 +186,10 @@ class ResNet(tnn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = tnn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
                                         pnn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample)]
+        layers = [block(self.inplanes, planes, stride, downsample, self.base_width)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
+            layers.append(block(self.inplanes, planes, base_width=self.base_width))
         return tnn.Sequential(*layers)
 
     def set_compute_dtype(self, dtype: torch.dtype) -> "ResNet":
@@ -221,12 +226,16 @@ _CFG = {
     "resnet50": (Bottleneck, [3, 4, 6, 3]),
     "resnet101": (Bottleneck, [3, 4, 23, 3]),
     "resnet152": (Bottleneck, [3, 8, 36, 3]),
+    "wide_resnet50_2": (Bottleneck, [3, 4, 6, 3]),
+    "wide_resnet101_2": (Bottleneck, [3, 4, 23, 3]),
 }
 
 
 def _make(name):
     def ctor(pretrained: bool = False, **kw) -> ResNet:
         block, layers = _CFG[name]
+        if name.startswith("wide_"):
+            kw.setdefault("width_per_group", 128)
         model = ResNet(block, layers, **kw)
         if pretrained:
             from . import load_pretrained
@@ -242,3 +251,5 @@ resnet34 = _make("resnet34")
 resnet50 = _make("resnet50")
 resnet101 = _make("resnet101")
 resnet152 = _make("resnet152")
+wide_resnet50_2 = _make("wide_resnet50_2")
+wide_resnet101_2 = _make("wide_resnet101_2")

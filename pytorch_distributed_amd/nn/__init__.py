@@ -138,12 +138,33 @@ class ReLU(tnn.Module):
 
 
 class MaxPool2d(tnn.Module):
-    def __init__(self, kernel_size: int, stride: Optional[int] = None, padding: int = 0):
+    def __init__(self, kernel_size: int, stride: Optional[int] = None, padding: int = 0, ceil_mode: bool = False):
         super().__init__()
         self.kernel_size, self.stride, self.padding = kernel_size, stride or kernel_size, padding
+        self.ceil_mode = ceil_mode
 
     def forward(self, x):
-        return ops.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+        return ops.max_pool2d(x, self.kernel_size, self.stride, self.padding, self.ceil_mode)
+
+
+class AvgPool2d(tnn.Module):
+    def __init__(self, kernel_size: int, stride: Optional[int] = None):
+        super().__init__()
+        self.kernel_size, self.stride = kernel_size, stride or kernel_size
+
+    def forward(self, x):
+        return ops.avg_pool2d(x, self.kernel_size, self.stride)
+
+
+class AdaptiveAvgPool2d(tnn.Module):
+    """[N,H,W,C] -> [N,oh,ow,C]."""
+
+    def __init__(self, output_size):
+        super().__init__()
+        self.output_size = output_size
+
+    def forward(self, x):
+        return ops.adaptive_avg_pool2d(x, self.output_size)
 
 
 class GlobalAvgPool2d(tnn.Module):
@@ -199,5 +220,6 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-__all__ = ["Conv2d", "BatchNorm2d", "SyncBatchNorm", "ConvBnAct", "ReLU", "MaxPool2d", "GlobalAvgPool2d", "Dropout",
+__all__ = ["Conv2d", "BatchNorm2d", "SyncBatchNorm", "ConvBnAct", "ReLU", "MaxPool2d", "AvgPool2d",
+           "AdaptiveAvgPool2d", "GlobalAvgPool2d", "Dropout",
            "Dropout2d", "Linear", "CrossEntropyLoss", "to_nhwc", "to_nchw"]

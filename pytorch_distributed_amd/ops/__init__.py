@@ -5,7 +5,7 @@ from . import _lib
 from .conv import conv2d, WeightCache, bump_param_generation, make_weight, krsc
 from .norm import batch_norm_act, BNState
 from .fused import conv_bn_act, stem_conv_bn_relu_pool, input_to_nhwc
-from .pool import max_pool2d, global_avg_pool
+from .pool import max_pool2d, global_avg_pool, avg_pool2d, adaptive_avg_pool2d
 from .loss import cross_entropy, log_softmax, nll_loss, new_metrics
 from .elementwise import relu, dropout, dropout2d
 from . import multi_tensor

@@ -12,12 +12,25 @@ from . import _lib
 from .conv import out_size
 
 
-def maxpool_fwd_gpu(x: torch.Tensor, k: int, s: int, p: int, scale=None, shift=None):
+def pool_out_size(i: int, k: int, s: int, p: int, ceil_mode: bool = False) -> int:
+    """Output length of a pooling window sweep; with ``ceil_mode`` a last, partial window is kept as long
+    as it starts inside the input or its left padding (the ``torch.nn.MaxPool2d`` rule)."""
+    if not ceil_mode:
+        return out_size(i, k, s, p)
+    o = -((i + 2 * p - k) // -s) + 1
+    if (o - 1) * s >= i + p:
+        o -= 1
+    return o
+
+
+def maxpool_fwd_gpu(x: torch.Tensor, k: int, s: int, p: int, scale=None, shift=None, ceil_mode: bool = False):
     """-> (pooled, arg-max bytes).  With ``scale``/``shift`` (fp32 [C]) the pooled quantity is
     ``relu(x*scale+shift)``: BatchNorm apply + ReLU + pool in one pass, without the full-size activation."""
     l = _lib.lib()
     N, H, W, Cc = x.shape
-    Ho, Wo = out_size(H, k, s, p), out_size(W, k, s, p)
+    if not 0 <= p <= k // 2 or k < 1 or s < 1 or H + 2 * p < k or W + 2 * p < k:
+        raise ValueError(f"max pool: window {k}, stride {s}, padding {p} do not fit a {H}x{W} input")
+    Ho, Wo = pool_out_size(H, k, s, p, ceil_mode), pool_out_size(W, k, s, p, ceil_mode)
     out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
     idx = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=torch.uint8)
     _lib.check(l.pda_maxpool_fwd(_lib.dt(x), x.data_ptr(), out.data_ptr(), idx.data_ptr(), N, H, W, Cc, Ho, Wo, k, s,
@@ -37,9 +50,9 @@ def maxpool_bwd_gpu(dout: torch.Tensor, idx: torch.Tensor, in_shape, k: int, s: 
 
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, k, s, p):
+    def forward(ctx, x, k, s, p, ceil_mode=False):
         x = x.contiguous()
-        out, idx = maxpool_fwd_gpu(x, k, s, p)
+        out, idx = maxpool_fwd_gpu(x, k, s, p, ceil_mode=ceil_mode)
         ctx.save_for_backward(idx)
         ctx.cfg = (tuple(x.shape), k, s, p)
         return out
@@ -48,14 +61,39 @@ class _MaxPoolFn(torch.autograd.Function):
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         shape, k, s, p = ctx.cfg
-        return maxpool_bwd_gpu(dout.contiguous(), idx, shape, k, s, p), None, None, None
+        return maxpool_bwd_gpu(dout.contiguous(), idx, shape, k, s, p), None, None, None, None
 
 
-def max_pool2d(x: torch.Tensor, k: int, s: int = None, p: int = 0) -> torch.Tensor:
+def max_pool2d(x: torch.Tensor, k: int, s: int = None, p: int = 0, ceil_mode: bool = False) -> torch.Tensor:
     s = k if s is None else s
     if not x.is_cuda:
-        return F.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
-    return _MaxPoolFn.apply(x, k, s, p)
+        return F.max_pool2d(x.permute(0, 3, 1, 2), k, s, p, ceil_mode=ceil_mode).permute(0, 2, 3, 1).contiguous()
+    return _MaxPoolFn.apply(x, k, s, p, ceil_mode)
+
+
+def avg_pool2d(x: torch.Tensor, k: int, s: int = None) -> torch.Tensor:
+    """Unpadded average pooling of an NHWC tensor (the 2x2 s2 pool of a DenseNet transition); a reshape and
+    an fp32-accumulated mean when the windows tile the input, stock pooling on a transposed view otherwise."""
+    s = k if s is None else s
+    N, H, W, Cc = x.shape
+    if s == k:
+        Ho, Wo = H // k, W // k
+        if (Ho * k, Wo * k) != (H, W):
+            x = x[:, :Ho * k, :Wo * k]
+        return x.reshape(N, Ho, k, Wo, k, Cc).mean(dim=(2, 4))
+    return F.avg_pool2d(x.permute(0, 3, 1, 2), k, s).permute(0, 2, 3, 1).contiguous()
+
+
+def adaptive_avg_pool2d(x: torch.Tensor, out_hw) -> torch.Tensor:
+    """``nn.AdaptiveAvgPool2d(out_hw)`` on an NHWC tensor: nothing to do when the map already has that
+    size (VGG / AlexNet at 224x224), the global-average kernel for (1, 1), stock pooling otherwise."""
+    oh, ow = (out_hw, out_hw) if isinstance(out_hw, int) else tuple(out_hw)
+    N, H, W, Cc = x.shape
+    if (H, W) == (oh, ow):
+        return x
+    if (oh, ow) == (1, 1):
+        return global_avg_pool(x).view(N, 1, 1, Cc)
+    return F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), (oh, ow)).permute(0, 2, 3, 1).contiguous()
 
 
 class _GapFn(torch.autograd.Function):

@@ -81,3 +81,12 @@ def test_style5_horovod(tmp_path):
 def test_style6_slurm_spawn(tmp_path):
     out = run([sys.executable, os.path.join(EX, "6_distributed_slurm.py")] + COMMON + ["--dist-file", "rdv"], tmp_path)
     assert " * Acc@1" in out and (tmp_path / "distributed.csv").exists()
+
+
+@pytest.mark.parametrize("arch", ["squeezenet1_1", "densenet121"])
+def test_other_arch_through_ddp_launcher(tmp_path, arch):
+    """``--arch`` reaches the other model families (/root/reference/2.distributed.py:28-33)."""
+    common = [a if a != "resnet18" else arch for a in COMMON]
+    out = run(LAUNCH + ["--nproc_per_node=2", "--master_port", str(free_port()), os.path.join(EX, "2_distributed.py")]
+              + common, tmp_path)
+    assert " * Acc@1" in out and (tmp_path / f"{arch}.checkpoint.pth.tar").exists()

@@ -1,0 +1,94 @@
+"""The dense-convolution torchvision families behind ``--arch`` (/root/reference/1.dataparallel.py:23-24):
+parameter counts and state_dict names against torchvision's published models, and one training step each.
+torchvision itself is not installed here, so the counts and key names below are its documented ones."""
+import pytest
+import torch
+
+from pytorch_distributed_amd import models
+
+PARAMS = {
+    "vgg11": 132863336, "vgg13": 133047848, "vgg16": 138357544, "vgg19": 143667240,
+    "vgg11_bn": 132868840, "vgg13_bn": 133053736, "vgg16_bn": 138365992, "vgg19_bn": 143678248,
+    "alexnet": 61100840, "squeezenet1_0": 1248424, "squeezenet1_1": 1235496,
+    "densenet121": 7978856, "densenet161": 28681000, "densenet169": 14149480, "densenet201": 20013928,
+    "wide_resnet50_2": 68883240, "wide_resnet101_2": 126886696,
+    "resnet18": 11689512, "resnet34": 21797672, "resnet50": 25557032, "resnet101": 44549160, "resnet152": 60192808,
+}
+KEYS = {
+    "vgg16": ["features.0.weight", "features.28.bias", "classifier.0.weight", "classifier.6.bias"],
+    "vgg16_bn": ["features.1.running_mean", "features.41.num_batches_tracked", "classifier.3.weight"],
+    "alexnet": ["features.0.weight", "features.10.bias", "classifier.1.weight", "classifier.6.weight"],
+    "squeezenet1_0": ["features.0.weight", "features.3.squeeze.weight", "features.12.expand3x3.bias",
+                      "classifier.1.weight"],
+    "squeezenet1_1": ["features.3.expand1x1.weight", "features.12.squeeze.bias", "classifier.1.bias"],
+    "densenet121": ["features.conv0.weight", "features.norm0.running_var",
+                    "features.denseblock1.denselayer1.norm1.weight", "features.denseblock4.denselayer16.conv2.weight",
+                    "features.transition3.conv.weight", "features.norm5.bias", "classifier.weight"],
+    "wide_resnet50_2": ["layer1.0.conv2.weight", "layer4.2.bn3.running_mean", "fc.weight"],
+}
+
+
+def test_every_arch_is_constructible_and_listed():
+    assert set(PARAMS) | {"mnist_net"} == set(models.model_names)
+    for name in models.model_names:
+        assert callable(getattr(models, name)) and models.__dict__[name] is getattr(models, name)
+
+
+@pytest.mark.parametrize("arch", sorted(PARAMS))
+def test_parameter_count_matches_torchvision(arch):
+    with torch.device("meta"):
+        m = models.get_model(arch)
+    assert sum(p.numel() for p in m.parameters()) == PARAMS[arch]
+
+
+@pytest.mark.parametrize("arch", sorted(KEYS))
+def test_state_dict_names(arch):
+    with torch.device("meta"):
+        sd = models.get_model(arch).state_dict()
+    for k in KEYS[arch]:
+        assert k in sd, (k, list(sd)[:8])
+    if arch == "wide_resnet50_2":
+        assert tuple(sd["layer1.0.conv2.weight"].shape) == (128, 128, 3, 3)
+        assert tuple(sd["layer1.0.conv3.weight"].shape) == (256, 128, 1, 1)
+    if arch == "densenet121":
+        assert tuple(sd["features.denseblock2.denselayer3.conv1.weight"].shape) == (128, 128 + 2 * 32, 1, 1)
+
+
+@pytest.mark.parametrize("arch,size,kw", [
+    ("vgg11_bn", 32, {"dropout": 0.0}), ("alexnet", 64, {}), ("squeezenet1_1", 48, {}), ("squeezenet1_0", 64, {}),
+    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {})])
+def test_one_training_step(arch, size, kw):
+    torch.manual_seed(0)
+    m = models.get_model(arch, num_classes=10, **kw)
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    x, y = torch.randn(2, 3, size, size), torch.tensor([1, 7])
+    out = m(x)
+    assert out.shape == (2, 10) and torch.isfinite(out).all()
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    missing = [n for n, p in m.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        assert m(x).shape == (2, 10)
+
+
+def test_ceil_mode_pool_matches_torch():
+    from pytorch_distributed_amd import ops
+    from pytorch_distributed_amd.ops.pool import pool_out_size
+    for h in range(3, 40):
+        for k, s, p in ((3, 2, 0), (3, 2, 1), (2, 2, 0)):
+            ref = torch.nn.functional.max_pool2d(torch.zeros(1, 1, h, h), k, s, p, ceil_mode=True).shape[-1]
+            assert pool_out_size(h, k, s, p, True) == ref, (h, k, s, p)
+    x = torch.randn(2, 13, 13, 8)
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert torch.equal(ops.max_pool2d(x, 3, 2, 0, True), ref)
+    a = torch.randn(2, 7, 6, 4)
+    assert torch.allclose(ops.avg_pool2d(a, 2, 2),
+                          torch.nn.functional.avg_pool2d(a.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1), atol=1e-6)
+    assert torch.allclose(ops.adaptive_avg_pool2d(a, (3, 3)),
+                          torch.nn.functional.adaptive_avg_pool2d(a.permute(0, 3, 1, 2), 3).permute(0, 2, 3, 1),
+                          atol=1e-6)
+    assert ops.adaptive_avg_pool2d(a, (7, 6)) is a

@@ -1,0 +1,95 @@
+"""The non-ResNet families on the HIP ops: the model on the GPU (hand-written kernels) against a copy of
+itself on the CPU (stock PyTorch math) with the same weights and inputs - loss, gradients, running
+statistics - plus one mixed-precision optimiser step."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pytorch_distributed_amd import models, ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _cos(a, b):
+    a, b = a.float().flatten().cpu(), b.float().flatten().cpu()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
+CASES = [("vgg11", 32, 4), ("vgg13_bn", 32, 8), ("alexnet", 96, 4), ("squeezenet1_0", 64, 4),
+         ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8)]
+
+
+@pytest.mark.parametrize("arch,hw,batch", CASES)
+def test_family_matches_cpu_math_fp32(arch, hw, batch):
+    torch.manual_seed(5)
+    kw = {} if arch.startswith(("densenet", "wide_")) else {"dropout": 0.0}
+    cpu = models.get_model(arch, num_classes=16, **kw)
+    gpu = copy.deepcopy(cpu).to(DEV)
+    x = torch.randn(batch, 3, hw, hw)
+    t = torch.randint(0, 16, (batch,))
+    lc = F.cross_entropy(cpu(x), t)
+    lg = ops.cross_entropy(gpu(x.to(DEV)), t.to(DEV))
+    assert abs(lc.item() - lg.item()) < 2e-3 * abs(lc.item()), (lc.item(), lg.item())
+    lc.backward()
+    lg.backward()
+    gc, gg = dict(cpu.named_parameters()), dict(gpu.named_parameters())
+    missing = [k for k in gg if gg[k].grad is None]
+    assert not missing, missing[:5]
+    allc = torch.cat([gc[k].grad.flatten() for k in gc])
+    allg = torch.cat([gg[k].grad.float().flatten().cpu() for k in gc])
+    cos = sorted((_cos(gg[k].grad, gc[k].grad), k) for k in gc if gc[k].grad.norm() > 1e-12)
+    assert _cos(allg, allc) > 0.999, (_cos(allg, allc), cos[:3])
+    assert cos[len(cos) // 2][0] > 0.999, cos[:3]
+    for (k, bc), (_, bg) in zip(cpu.named_buffers(), gpu.named_buffers()):
+        if k.endswith("running_var"):
+            assert torch.allclose(bg.cpu(), bc, rtol=2e-3, atol=1e-5), k
+            break
+
+
+@pytest.mark.parametrize("arch,hw,batch", [("vgg11_bn", 32, 8), ("squeezenet1_1", 64, 8), ("densenet121", 64, 8),
+                                           ("alexnet", 96, 8)])
+def test_family_amp_step(arch, hw, batch):
+    """fp16 O2 + fused SGD: finite loss, every parameter moves, a second step lowers the loss on the same batch."""
+    from pytorch_distributed_amd import amp
+    from pytorch_distributed_amd.optim import FusedSGD
+    torch.manual_seed(6)
+    kw = {} if arch.startswith("densenet") else {"dropout": 0.0}
+    m = models.get_model(arch, num_classes=16, **kw).to(DEV)
+    opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    m, opt = amp.initialize(m, opt, opt_level="O2", verbosity=0)
+    x = torch.randn(batch, 3, hw, hw, device=DEV)
+    t = torch.randint(0, 16, (batch,), device=DEV)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = ops.cross_entropy(m(x), t)
+        with amp.scale_loss(loss, opt) as scaled:
+            scaled.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l and abs(l) != float("inf") for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    moved = [k for k, p in m.named_parameters() if not torch.equal(p.detach(), before[k])]
+    assert len(moved) == len(before), set(before) - set(moved)
+
+
+def test_ceil_mode_and_avg_pools_gpu():
+    torch.manual_seed(7)
+    for dtype in (torch.float32, torch.float16):
+        x = torch.randn(3, 13, 15, 16, device=DEV, dtype=dtype, requires_grad=True)
+        y = ops.max_pool2d(x, 3, 2, 0, True)
+        xr = x.detach().float().cpu().requires_grad_(True)
+        yr = F.max_pool2d(xr.permute(0, 3, 1, 2), 3, 2, ceil_mode=True).permute(0, 2, 3, 1)
+        assert y.shape == yr.shape and torch.equal(y.float().cpu(), yr)
+        g = torch.randn_like(yr)
+        y.backward(g.to(DEV, dtype))
+        yr.backward(g)
+        assert torch.allclose(x.grad.float().cpu(), xr.grad, atol=2e-2 if dtype == torch.float16 else 1e-6)
+    a = torch.randn(2, 8, 8, 32, device=DEV)
+    assert torch.allclose(ops.avg_pool2d(a, 2, 2), F.avg_pool2d(a.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1),
+                          atol=1e-6)
+    assert torch.allclose(ops.adaptive_avg_pool2d(a, (1, 1)).flatten(1), a.mean(dim=(1, 2)), atol=1e-5)
