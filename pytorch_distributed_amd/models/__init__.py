@@ -9,17 +9,17 @@ import os
 import torch
 
 from .resnet import (ResNet, BasicBlock, Bottleneck, resnet18, resnet34, resnet50, resnet101, resnet152,
-                     wide_resnet50_2, wide_resnet101_2)
+                     wide_resnet50_2, wide_resnet101_2, resnext50_32x4d, resnext101_32x8d, resnext101_64x4d)
 from .vgg import VGG, AlexNet, alexnet, vgg11, vgg11_bn, vgg13, vgg13_bn, vgg16, vgg16_bn, vgg19, vgg19_bn
 from .squeezenet import SqueezeNet, squeezenet1_0, squeezenet1_1
 from .densenet import DenseNet, densenet121, densenet161, densenet169, densenet201
 from .mnist import Net, mnist_net
 from .reference import torch_resnet, TorchResNet
 
-# Families built from dense convolutions.  torchvision's grouped / depthwise families (resnext*,
-# mobilenet*, shufflenet*, mnasnet*) and the multi-branch Inception / GoogLeNet are not provided.
+# Families built from dense and grouped convolutions.  torchvision's depthwise families (mobilenet*,
+# shufflenet*, mnasnet*) and the multi-branch Inception / GoogLeNet are not provided.
 model_names = sorted(["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "wide_resnet50_2",
-                      "wide_resnet101_2", "alexnet", "vgg11", "vgg11_bn", "vgg13", "vgg13_bn", "vgg16", "vgg16_bn",
+                      "wide_resnet101_2", "resnext50_32x4d", "resnext101_32x8d", "resnext101_64x4d", "alexnet", "vgg11", "vgg11_bn", "vgg13", "vgg13_bn", "vgg16", "vgg16_bn",
                       "vgg19", "vgg19_bn", "squeezenet1_0", "squeezenet1_1", "densenet121", "densenet161",
                       "densenet169", "densenet201", "mnist_net"])
 

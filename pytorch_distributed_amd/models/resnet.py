@@ -1,5 +1,5 @@
-"""ResNet-18/34/50/101/152 and Wide-ResNet-50-2/101-2 (torchvision v1.5 topology: stride on
-the 3x3 of a bottleneck) built on the fused NHWC ops.
+"""ResNet-18/34/50/101/152, Wide-ResNet-50-2/101-2 and ResNeXt-50 32x4d / 101 32x8d / 101 64x4d
+(torchvision v1.5 topology: stride on the 3x3 of a bottleneck) built on the fused NHWC ops.
 
 ``state_dict()`` keys, shapes and dtypes are those of torchvision's ResNet
 (``conv1.weight``, ``layer1.0.bn1.running_mean``, ``layer2.0.downsample.0.weight``,
@@ -25,8 +25,8 @@ from .. import ops
 from ..ops.fused import BNBackwardLink
 
 
-def _conv3x3(cin, cout, stride=1):
-    return pnn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+def _conv3x3(cin, cout, stride=1, groups=1):
+    return pnn.Conv2d(cin, cout, 3, stride, 1, bias=False, groups=groups)
 
 
 def _conv1x1(cin, cout, stride=1):
@@ -60,10 +60,11 @@ def _links(block, n_inner: int):
 class BasicBlock(tnn.Module):
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64):
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64,
+                 groups: int = 1):
         super().__init__()
-        if base_width != 64:
-            raise ValueError("BasicBlock only supports base_width=64")
+        if base_width != 64 or groups != 1:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
         self.conv1 = _conv3x3(inplanes, planes, stride)
         self.bn1 = pnn.BatchNorm2d(planes)
         self.relu = pnn.ReLU()
@@ -89,12 +90,15 @@ class BasicBlock(tnn.Module):
 class Bottleneck(tnn.Module):
     expansion = 4
 
-    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64):
+    def __init__(self, inplanes, planes, stride=1, downsample: Optional[tnn.Module] = None, base_width: int = 64,
+                 groups: int = 1):
         super().__init__()
-        width = planes * base_width // 64     # wide_resnet*_2: twice the inner (3x3) width, same block output
+        # wide_resnet*_2: twice the inner (3x3) width, same block output; resnext: `groups` groups of
+        # `base_width * planes / 64` channels in the 3x3
+        width = planes * base_width // 64 * groups
         self.conv1 = _conv1x1(inplanes, width)
         self.bn1 = pnn.BatchNorm2d(width)
-        self.conv2 = _conv3x3(width, width, stride)
+        self.conv2 = _conv3x3(width, width, stride, groups)
         self.bn2 = pnn.BatchNorm2d(width)
         self.conv3 = _conv1x1(width, planes * self.expansion)
         self.bn3 = pnn.BatchNorm2d(planes * self.expansion)
@@ -119,10 +123,11 @@ class Bottleneck(tnn.Module):
 class ResNet(tnn.Module):
     def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], num_classes: int = 1000,
                  zero_init_residual: bool = False, input_mean=None, input_std=None, input_scale: float = 1.0,
-                 width_per_group: int = 64):
+                 width_per_group: int = 64, groups: int = 1):
         super().__init__()
         self.inplanes = 64
         self.base_width = width_per_group
+        self.groups = groups
         self.conv1 = pnn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = pnn.BatchNorm2d(64)
         self.relu = pnn.ReLU()
@@ -186,10 +191,10 @@ class ResNet(tnn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = tnn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
                                         pnn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample, self.base_width)]
+        layers = [block(self.inplanes, planes, stride, downsample, self.base_width, self.groups)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, base_width=self.base_width))
+            layers.append(block(self.inplanes, planes, base_width=self.base_width, groups=self.groups))
         return tnn.Sequential(*layers)
 
     def set_compute_dtype(self, dtype: torch.dtype) -> "ResNet":
@@ -228,14 +233,20 @@ _CFG = {
     "resnet152": (Bottleneck, [3, 8, 36, 3]),
     "wide_resnet50_2": (Bottleneck, [3, 4, 6, 3]),
     "wide_resnet101_2": (Bottleneck, [3, 4, 23, 3]),
+    "resnext50_32x4d": (Bottleneck, [3, 4, 6, 3]),
+    "resnext101_32x8d": (Bottleneck, [3, 4, 23, 3]),
+    "resnext101_64x4d": (Bottleneck, [3, 4, 23, 3]),
 }
+_WIDTHS = {"wide_resnet50_2": (1, 128), "wide_resnet101_2": (1, 128), "resnext50_32x4d": (32, 4),
+           "resnext101_32x8d": (32, 8), "resnext101_64x4d": (64, 4)}
 
 
 def _make(name):
     def ctor(pretrained: bool = False, **kw) -> ResNet:
         block, layers = _CFG[name]
-        if name.startswith("wide_"):
-            kw.setdefault("width_per_group", 128)
+        if name in _WIDTHS:
+            kw.setdefault("groups", _WIDTHS[name][0])
+            kw.setdefault("width_per_group", _WIDTHS[name][1])
         model = ResNet(block, layers, **kw)
         if pretrained:
             from . import load_pretrained
@@ -253,3 +264,6 @@ resnet101 = _make("resnet101")
 resnet152 = _make("resnet152")
 wide_resnet50_2 = _make("wide_resnet50_2")
 wide_resnet101_2 = _make("wide_resnet101_2")
+resnext50_32x4d = _make("resnext50_32x4d")
+resnext101_32x8d = _make("resnext101_32x8d")
+resnext101_64x4d = _make("resnext101_64x4d")

@@ -21,13 +21,16 @@ from ..ops.norm import BNState
 
 
 class Conv2d(tnn.Module):
-    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, bias: bool = True):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride=1, padding=0, bias: bool = True,
+                 groups: int = 1):
         super().__init__()
         ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
-        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        if in_channels % groups or out_channels % groups:
+            raise ValueError("in_channels and out_channels must be divisible by groups")
+        self.in_channels, self.out_channels, self.kernel_size, self.groups = in_channels, out_channels, ks, groups
         self.stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
         self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
-        self.weight = tnn.Parameter(_conv.make_weight(out_channels, in_channels, ks[0], ks[1]))
+        self.weight = tnn.Parameter(_conv.make_weight(out_channels, in_channels // groups, ks[0], ks[1]))
         self.bias = tnn.Parameter(torch.empty(out_channels)) if bias else None
         self._cache = _conv.WeightCache()
         self.reset_parameters()
@@ -35,16 +38,16 @@ class Conv2d(tnn.Module):
     def reset_parameters(self) -> None:
         tnn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+            fan_in = self.in_channels // self.groups * self.kernel_size[0] * self.kernel_size[1]
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             tnn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache, self.groups)
 
     def extra_repr(self) -> str:
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
-                f"padding={self.padding}, bias={self.bias is not None}, layout=NHWC")
+                f"padding={self.padding}, groups={self.groups}, bias={self.bias is not None}, layout=NHWC")
 
 
 class BatchNorm2d(tnn.Module):
@@ -114,7 +117,7 @@ class ConvBnAct(tnn.Module):
             dout_premasked: bool = False, in_link=None, out_link=None):
         """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
-        if conv.bias is not None:
+        if conv.bias is not None or conv.groups != 1:
             # unfused modules: the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
             # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
             # gradient mask on x

@@ -461,8 +461,11 @@ def conv2d_ref(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad) -> torc
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=(0, 0),
-           cache: Optional[WeightCache] = None) -> torch.Tensor:
-    """NHWC convolution. ``weight`` is logical [K,C,R,S]."""
+           cache: Optional[WeightCache] = None, groups: int = 1) -> torch.Tensor:
+    """NHWC convolution. ``weight`` is logical [K,C/groups,R,S]."""
+    if groups != 1:
+        from .grouped import grouped_conv2d
+        return grouped_conv2d(x, weight, bias, stride, pad, groups)
     if not x.is_cuda:
         return conv2d_ref(x, weight, bias, stride, pad)
     return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())

@@ -19,13 +19,13 @@ def _cos(a, b):
 
 
 CASES = [("vgg11", 32, 4), ("vgg13_bn", 32, 8), ("alexnet", 96, 4), ("squeezenet1_0", 64, 4),
-         ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8)]
+         ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8), ("resnext50_32x4d", 64, 8)]
 
 
 @pytest.mark.parametrize("arch,hw,batch", CASES)
 def test_family_matches_cpu_math_fp32(arch, hw, batch):
     torch.manual_seed(5)
-    kw = {} if arch.startswith(("densenet", "wide_")) else {"dropout": 0.0}
+    kw = {} if arch.startswith(("densenet", "wide_", "resnext")) else {"dropout": 0.0}
     cpu = models.get_model(arch, num_classes=16, **kw)
     gpu = copy.deepcopy(cpu).to(DEV)
     x = torch.randn(batch, 3, hw, hw)
@@ -50,13 +50,13 @@ def test_family_matches_cpu_math_fp32(arch, hw, batch):
 
 
 @pytest.mark.parametrize("arch,hw,batch", [("vgg11_bn", 32, 8), ("squeezenet1_1", 64, 8), ("densenet121", 64, 8),
-                                           ("alexnet", 96, 8)])
+                                           ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8)])
 def test_family_amp_step(arch, hw, batch):
     """fp16 O2 + fused SGD: finite loss, every parameter moves, a second step lowers the loss on the same batch."""
     from pytorch_distributed_amd import amp
     from pytorch_distributed_amd.optim import FusedSGD
     torch.manual_seed(6)
-    kw = {} if arch.startswith("densenet") else {"dropout": 0.0}
+    kw = {} if arch.startswith(("densenet", "resnext")) else {"dropout": 0.0}
     m = models.get_model(arch, num_classes=16, **kw).to(DEV)
     opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     m, opt = amp.initialize(m, opt, opt_level="O2", verbosity=0)
@@ -93,3 +93,33 @@ def test_ceil_mode_and_avg_pools_gpu():
     assert torch.allclose(ops.avg_pool2d(a, 2, 2), F.avg_pool2d(a.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1),
                           atol=1e-6)
     assert torch.allclose(ops.adaptive_avg_pool2d(a, (1, 1)).flatten(1), a.mean(dim=(1, 2)), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,groups,stride,bias", [(128, 128, 32, 1, False), (256, 256, 32, 2, False),
+                                                        (64, 128, 8, 1, True)])
+def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
+    """Block-diagonal expansion on the MFMA kernels == F.conv2d(groups=...) in fp32."""
+    torch.manual_seed(8)
+    x = torch.randn(4, 14, 14, cin, device=DEV, dtype=dtype, requires_grad=True)
+    w = (torch.randn(cout, cin // groups, 3, 3, device=DEV) * 0.1).requires_grad_(True)
+    b = torch.randn(cout, device=DEV, requires_grad=True) if bias else None
+    y = ops.conv2d(x, w, b, (stride, stride), (1, 1), groups=groups)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=1, groups=groups)
+    tol = 1e-4 if dtype == torch.float32 else (2e-2 if dtype == torch.float16 else 5e-2)
+    assert y.shape == yr.permute(0, 2, 3, 1).shape
+
+    def rel(a, r):
+        a, r = a.detach().float(), r.detach()
+        return float((a - r).norm() / (r.norm() + 1e-30))
+    assert rel(y, yr.permute(0, 2, 3, 1)) < tol
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+    yr.backward(g.to(dtype).float())
+    assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+    assert w.grad.shape == wr.grad.shape and rel(w.grad, wr.grad) < tol
+    if bias:
+        assert rel(b.grad, br.grad) < tol
