@@ -50,6 +50,22 @@ relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     dx[i] = ElemTraits<T>::to_f32(y[i]) > 0.f ? dy[i] : ElemTraits<T>::from_f32(0.f);
 }
+// ReLU6-style clipped activation: y = min(max(x, 0), cap); gradient passes where 0 < y < cap
+// (torch.nn.functional.hardtanh's rule: nothing at the two ends).
+template <typename T>
+__global__ void __launch_bounds__(256)
+relu_cap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float cap) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = ElemTraits<T>::from_f32(fminf(fmaxf(ElemTraits<T>::to_f32(x[i]), 0.f), cap));
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+relu_cap_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n, float cap) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = ElemTraits<T>::to_f32(y[i]);
+    dx[i] = (v > 0.f && v < cap) ? dy[i] : ElemTraits<T>::from_f32(0.f);
+  }
+}
 template <typename T>
 __global__ void __launch_bounds__(256)
 add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n, int relu) {
@@ -202,6 +218,17 @@ PDA_EXPORT int pda_relu_fwd(int dtype, const void* x, void* y, long long n, hipS
 PDA_EXPORT int pda_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, hipStream_t st) {
   if (n == 0) return 0;
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_relu_cap_fwd(int dtype, const void* x, void* y, long long n, float cap, hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n, cap));
+  return pda_check_launch();
+}
+PDA_EXPORT int pda_relu_cap_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, float cap,
+                                hipStream_t st) {
+  if (n == 0) return 0;
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n, cap));
   return pda_check_launch();
 }
 // srcs: array of nsrc (<= 8) device pointers, all 16-byte aligned like out; out may alias srcs[0].

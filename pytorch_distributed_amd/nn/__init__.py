@@ -117,8 +117,9 @@ class ConvBnAct(tnn.Module):
             dout_premasked: bool = False, in_link=None, out_link=None):
         """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
-        if conv.bias is not None or conv.groups != 1:
-            # unfused modules: the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
+        if conv.bias is not None or conv.groups != 1 or conv.out_channels % 8 \
+                or not _conv.igemm_tiles(conv.in_channels, x.dtype):
+            # unfused modules (a bias, groups, or a channel count the MFMA kernels do not tile): the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
             # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
             # gradient mask on x
             if (mask_dx or (in_link is not None and in_link.relu)) and x.is_cuda:
@@ -138,6 +139,14 @@ class ReLU(tnn.Module):
 
     def forward(self, x):
         return ops.relu(x)
+
+
+class ReLU6(tnn.Module):
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        return ops.relu6(x)
 
 
 class MaxPool2d(tnn.Module):
@@ -223,6 +232,6 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-__all__ = ["Conv2d", "BatchNorm2d", "SyncBatchNorm", "ConvBnAct", "ReLU", "MaxPool2d", "AvgPool2d",
+__all__ = ["Conv2d", "BatchNorm2d", "SyncBatchNorm", "ConvBnAct", "ReLU", "ReLU6", "MaxPool2d", "AvgPool2d",
            "AdaptiveAvgPool2d", "GlobalAvgPool2d", "Dropout",
            "Dropout2d", "Linear", "CrossEntropyLoss", "to_nhwc", "to_nchw"]

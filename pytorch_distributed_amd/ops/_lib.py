@@ -38,6 +38,8 @@ _SIGS = {
     "pda_krsc_to_crsk_batched": [c_i, c_i, c_p, c_p, c_i, c_p],
     "pda_direct_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                         c_i, c_i, c_p],
+    "pda_depthwise_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                           c_i, c_i, c_p],
     "pda_bn_num_partials": [c_ll, c_i, c_i],
     "pda_bn_stats_partial": [c_i, c_p, c_ll, c_i, c_p, c_p, c_p],
     "pda_bn_reduce_partials": [c_p, c_p, c_i, c_i, c_p, c_i, c_p],
@@ -67,6 +69,8 @@ _SIGS = {
     "pda_nchw_to_nhwc": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p],
     "pda_relu_fwd": [c_i, c_p, c_p, c_ll, c_p],
     "pda_relu_bwd": [c_i, c_p, c_p, c_p, c_ll, c_p],
+    "pda_relu_cap_fwd": [c_i, c_p, c_p, c_ll, ctypes.c_float, c_p],
+    "pda_relu_cap_bwd": [c_i, c_p, c_p, c_p, c_ll, ctypes.c_float, c_p],
     "pda_add": [c_i, c_p, c_p, c_p, c_ll, c_i, c_p],
     "pda_add_n": [c_i, c_p, c_i, c_p, c_ll, c_p],
     "pda_bias_add": [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],

@@ -468,4 +468,15 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
         return grouped_conv2d(x, weight, bias, stride, pad, groups)
     if not x.is_cuda:
         return conv2d_ref(x, weight, bias, stride, pad)
+    K, Cin, R, S = weight.shape
+    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not igemm_tiles(Cin, x.dtype):
+        # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
+        # do not tile (24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
+        return F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
     return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())
+
+
+def igemm_tiles(channels: int, dtype: torch.dtype) -> bool:
+    """Whether the MFMA implicit-GEMM kernels can step through ``channels`` input channels: their K step is
+    64 bytes of one filter tap (32 16-bit or 16 fp32 channels)."""
+    return channels % (64 // torch.empty((), dtype=dtype).element_size()) == 0

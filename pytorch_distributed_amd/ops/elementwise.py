@@ -41,6 +41,34 @@ def relu(x: torch.Tensor) -> torch.Tensor:
     return torch.relu(x) if not x.is_cuda else _ReluFn.apply(x)
 
 
+class _ReluCapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cap):
+        l = _lib.lib()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _lib.check(l.pda_relu_cap_fwd(_lib.dt(x), x.data_ptr(), y.data_ptr(), x.numel(), cap, _lib.stream()),
+                   "pda_relu_cap_fwd")
+        ctx.save_for_backward(y)
+        ctx.cap = cap
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        l = _lib.lib()
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(l.pda_relu_cap_bwd(_lib.dt(dy), dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), ctx.cap,
+                                      _lib.stream()), "pda_relu_cap_bwd")
+        return dx, None
+
+
+def relu6(x: torch.Tensor) -> torch.Tensor:
+    """``min(max(x, 0), 6)`` (MobileNet's activation)."""
+    return F.hardtanh(x, 0.0, 6.0) if not x.is_cuda else _ReluCapFn.apply(x, 6.0)
+
+
 def _launch_dropout(x, p, seed, offset, channel_mode, per_image, Cc):
     l = _lib.lib()
     y = torch.empty_like(x)

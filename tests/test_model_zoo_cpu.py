@@ -13,6 +13,7 @@ PARAMS = {
     "densenet121": 7978856, "densenet161": 28681000, "densenet169": 14149480, "densenet201": 20013928,
     "wide_resnet50_2": 68883240, "wide_resnet101_2": 126886696,
     "resnext50_32x4d": 25028904, "resnext101_32x8d": 88791336, "resnext101_64x4d": 83455272,
+    "mobilenet_v2": 3504872,
     "resnet18": 11689512, "resnet34": 21797672, "resnet50": 25557032, "resnet101": 44549160, "resnet152": 60192808,
 }
 KEYS = {
@@ -27,6 +28,9 @@ KEYS = {
                     "features.transition3.conv.weight", "features.norm5.bias", "classifier.weight"],
     "wide_resnet50_2": ["layer1.0.conv2.weight", "layer4.2.bn3.running_mean", "fc.weight"],
     "resnext50_32x4d": ["layer1.0.conv2.weight", "layer4.2.conv2.weight", "fc.bias"],
+    "mobilenet_v2": ["features.0.0.weight", "features.1.conv.0.0.weight", "features.1.conv.1.weight",
+                     "features.2.conv.1.0.weight", "features.17.conv.3.running_var", "features.18.1.running_mean",
+                     "classifier.1.weight"],
 }
 
 
@@ -55,13 +59,15 @@ def test_state_dict_names(arch):
     if arch == "resnext50_32x4d":
         assert tuple(sd["layer1.0.conv2.weight"].shape) == (128, 4, 3, 3)
         assert tuple(sd["layer4.2.conv2.weight"].shape) == (1024, 32, 3, 3)
+    if arch == "mobilenet_v2":
+        assert tuple(sd["features.2.conv.1.0.weight"].shape) == (96, 1, 3, 3)
     if arch == "densenet121":
         assert tuple(sd["features.denseblock2.denselayer3.conv1.weight"].shape) == (128, 128 + 2 * 32, 1, 1)
 
 
 @pytest.mark.parametrize("arch,size,kw", [
     ("vgg11_bn", 32, {"dropout": 0.0}), ("alexnet", 64, {}), ("squeezenet1_1", 48, {}), ("squeezenet1_0", 64, {}),
-    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {})])
+    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {}), ("mobilenet_v2", 64, {})])
 def test_one_training_step(arch, size, kw):
     torch.manual_seed(0)
     m = models.get_model(arch, num_classes=10, **kw)

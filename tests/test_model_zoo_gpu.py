@@ -19,7 +19,8 @@ def _cos(a, b):
 
 
 CASES = [("vgg11", 32, 4), ("vgg13_bn", 32, 8), ("alexnet", 96, 4), ("squeezenet1_0", 64, 4),
-         ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8), ("resnext50_32x4d", 64, 8)]
+         ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8), ("resnext50_32x4d", 64, 8),
+         ("mobilenet_v2", 64, 8)]
 
 
 @pytest.mark.parametrize("arch,hw,batch", CASES)
@@ -50,7 +51,7 @@ def test_family_matches_cpu_math_fp32(arch, hw, batch):
 
 
 @pytest.mark.parametrize("arch,hw,batch", [("vgg11_bn", 32, 8), ("squeezenet1_1", 64, 8), ("densenet121", 64, 8),
-                                           ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8)])
+                                           ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8), ("mobilenet_v2", 64, 8)])
 def test_family_amp_step(arch, hw, batch):
     """fp16 O2 + fused SGD: finite loss, every parameter moves, a second step lowers the loss on the same batch."""
     from pytorch_distributed_amd import amp
@@ -123,3 +124,56 @@ def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
     assert w.grad.shape == wr.grad.shape and rel(w.grad, wr.grad) < tol
     if bias:
         assert rel(b.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ch,k,stride,pad,hw,bias", [(96, 3, 1, 1, 14, False), (144, 3, 2, 1, 15, False),
+                                                    (32, 5, 2, 2, 12, True), (20, 3, 1, 1, 9, False)])
+def test_depthwise_conv_matches_reference(dtype, ch, k, stride, pad, hw, bias):
+    """Depthwise kernels (vector path for channel counts that fill 16-byte vectors, scalar otherwise)
+    == F.conv2d(groups=C) in fp32; also the single-slab (deterministic) weight gradient."""
+    from pytorch_distributed_amd import backends
+    torch.manual_seed(9)
+    x = torch.randn(6, hw, hw + 1, ch, device=DEV, dtype=dtype, requires_grad=True)
+    w = (torch.randn(ch, 1, k, k, device=DEV) * 0.3).requires_grad_(True)
+    b = torch.randn(ch, device=DEV, requires_grad=True) if bias else None
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, groups=ch)
+    g = torch.randn_like(yr)
+    yr.backward(g.to(dtype).float())
+    tol = 1e-5 if dtype == torch.float32 else (5e-3 if dtype == torch.float16 else 3e-2)
+
+    def rel(a, r):
+        a, r = a.detach().float(), r.detach()
+        return float((a - r).norm() / (r.norm() + 1e-30))
+    for det in (False, True):
+        backends.deterministic = det
+        try:
+            x.grad = w.grad = None
+            if bias:
+                b.grad = None
+            y = ops.conv2d(x, w, b, (stride, stride), (pad, pad), groups=ch)
+            assert y.shape == yr.permute(0, 2, 3, 1).shape
+            assert rel(y, yr.permute(0, 2, 3, 1)) < tol
+            y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+        finally:
+            backends.deterministic = False
+        assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+        assert w.grad.shape == wr.grad.shape and rel(w.grad, wr.grad) < max(tol, 1e-5)
+        if bias:
+            assert rel(b.grad, br.grad) < tol
+
+
+def test_relu6_matches_hardtanh():
+    for dtype in (torch.float32, torch.float16):
+        x = (torch.randn(5, 7, 7, 24, device=DEV) * 4).to(dtype).requires_grad_(True)
+        y = ops.relu6(x)
+        xr = x.detach().clone().requires_grad_(True)
+        yr = F.hardtanh(xr, 0.0, 6.0)
+        assert torch.equal(y, yr)
+        g = torch.randn_like(y)
+        y.backward(g)
+        yr.backward(g)
+        assert torch.equal(x.grad, xr.grad)
