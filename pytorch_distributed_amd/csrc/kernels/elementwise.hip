@@ -122,19 +122,27 @@ bias_add_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __re
     y[i] = ElemTraits<T>::from_f32(v);
   }
 }
-// dbias[c] = sum over rows of dy[m][c]   (any C; one block per 64 channels)
+// dbias[c] = sum over rows of dy[m][c]   (any C; grid.x = 64-channel groups, grid.y = row slabs).
+// One slab: plain store.  Several slabs (a first-layer conv has millions of rows and 64 channels - one
+// workgroup per 64 channels would leave the chip idle): float atomics into the zero-filled output.
 template <typename T>
 __global__ void __launch_bounds__(256)
-colsum_kernel(const T* __restrict__ dy, float* __restrict__ out, long long M, int C) {
+colsum_kernel(const T* __restrict__ dy, float* __restrict__ out, long long M, int C, long long slab) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
+  const long long m0 = (long long)blockIdx.y * slab;
+  const long long m1 = m0 + slab < M ? m0 + slab : M;
   float acc = 0.f;
   if (c < C)
-    for (long long m = rl; m < M; m += 4) acc += ElemTraits<T>::to_f32(dy[m * C + c]);
+    for (long long m = m0 + rl; m < m1; m += 4) acc += ElemTraits<T>::to_f32(dy[m * C + c]);
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (rl == 0 && c < C) out[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (rl == 0 && c < C) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (gridDim.y > 1) atomicAdd(out + c, t);
+    else out[c] = t;
+  }
 }
 
 // ---- Philox4x32-10 ---------------------------------------------------------
@@ -260,9 +268,25 @@ PDA_EXPORT int pda_bias_add(int dtype, const void* x, const float* bias, void* y
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bias_add_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, C, relu));
   return pda_check_launch();
 }
-PDA_EXPORT int pda_colsum(int dtype, const void* dy, float* out, long long M, int C, hipStream_t st) {
+// one_slab != 0: a single workgroup per 64 channels sums all rows (no atomics: bit-reproducible).
+PDA_EXPORT int pda_colsum(int dtype, const void* dy, float* out, long long M, int C, int one_slab, hipStream_t st) {
   if (C == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3((C + 63) / 64), dim3(256), 0, st, (const T*)dy, out, M, C));
+  const int gx = (C + 63) / 64;
+  long long ns = 1;
+  if (!one_slab) {
+    ns = 2048 / gx;                           // ~8 workgroups per CU
+    const long long cap = (M + 1023) / 1024;  // at least 256 rows per row lane
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+  }
+  const long long slab = M > 0 ? (M + ns - 1) / ns : 1;
+  const unsigned gy = M > 0 ? (unsigned)((M + slab - 1) / slab) : 1u;
+  if (gy > 1) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, st, (const T*)dy, out, M, C, slab));
   return pda_check_launch();
 }
 PDA_EXPORT int pda_dropout(int dtype, const void* x, void* y, long long n, float p, unsigned long long seed,

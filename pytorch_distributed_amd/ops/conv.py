@@ -448,7 +448,8 @@ class _Conv2dFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             l = _lib.lib()
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
-            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), N * Ho * Wo, K, _lib.stream()),
+            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), N * Ho * Wo, K,
+                                    int(backends.deterministic), _lib.stream()),
                        "pda_colsum")
         return dx, dw, db, None, None, None
 
@@ -473,6 +474,16 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
         # do not tile (24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
         return F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
+    if K % 8 == 0 and not igemm_tiles(Cin, x.dtype):
+        # an image (3 channels) or a narrow feature map (16, 48 channels in 16-bit): zero-pad the channels of
+        # the activation and of the filter up to the kernels' K step and run on the matrix cores - the padded
+        # FLOPs are cheaper than the scalar fallback by orders of magnitude (the padding is differentiable: the
+        # gradients of the real channels come back through the slice).  A fresh cache: the padded filter is a
+        # temporary, nothing about it may be remembered across calls.
+        step = 64 // x.element_size()
+        extra = -Cin % step
+        return _Conv2dFn.apply(F.pad(x, (0, extra)), F.pad(weight, (0, 0, 0, 0, 0, extra)), bias, tuple(stride),
+                               tuple(pad), WeightCache())
     return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())
 
 

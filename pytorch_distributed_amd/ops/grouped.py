@@ -66,6 +66,7 @@ class _GroupedConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        from .. import backends
         x, weight = ctx.saved_tensors
         stride, pad, groups, has_bias = ctx.cfg
         dy = dy.contiguous()
@@ -84,7 +85,8 @@ class _GroupedConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             l = _lib.lib()
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
-            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // K, K, _lib.stream()),
+            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // K, K,
+                                    int(backends.deterministic), _lib.stream()),
                        "pda_colsum")
         return dx, dw, db, None, None, None
 
@@ -130,7 +132,8 @@ class _DepthwiseConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             l = _lib.lib()
             db = torch.empty(Cc, device=dy.device, dtype=torch.float32)
-            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // Cc, Cc, _lib.stream()),
+            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // Cc, Cc,
+                                    int(backends.deterministic), _lib.stream()),
                        "pda_colsum")
         return dx, dw, db, None, None
 
