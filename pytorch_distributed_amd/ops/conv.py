@@ -470,7 +470,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
     if not x.is_cuda:
         return conv2d_ref(x, weight, bias, stride, pad)
     K, Cin, R, S = weight.shape
-    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not igemm_tiles(Cin, x.dtype):
+    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) \
+            and (K % 8 != 0 or not igemm_tiles(Cin, x.dtype)):
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
         # do not tile (24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
         return F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))

@@ -315,6 +315,7 @@ def _sync_bn_ref(x, gamma, beta, st: BNState, mom):
 
 
 def batch_norm_act(y, gamma, beta, residual, relu: bool, st: BNState):
-    if not y.is_cuda:
+    if not y.is_cuda or y.shape[-1] % (16 // y.element_size()) != 0:
+        # CPU, or a channel count that does not fill 16-byte vectors (58, 122 in ShuffleNetV2): stock math
         return batch_norm_act_ref(y, gamma, beta, residual, relu, st)
     return _BatchNormActFn.apply(y, gamma, beta, residual, relu, st)

@@ -14,6 +14,9 @@ PARAMS = {
     "wide_resnet50_2": 68883240, "wide_resnet101_2": 126886696,
     "resnext50_32x4d": 25028904, "resnext101_32x8d": 88791336, "resnext101_64x4d": 83455272,
     "mobilenet_v2": 3504872,
+    "shufflenet_v2_x0_5": 1366792, "shufflenet_v2_x1_0": 2278604, "shufflenet_v2_x1_5": 3503624,
+    "shufflenet_v2_x2_0": 7393996,
+    "mnasnet0_5": 2218512, "mnasnet0_75": 3170208, "mnasnet1_0": 4383312, "mnasnet1_3": 6282256,
     "resnet18": 11689512, "resnet34": 21797672, "resnet50": 25557032, "resnet101": 44549160, "resnet152": 60192808,
 }
 KEYS = {
@@ -28,6 +31,11 @@ KEYS = {
                     "features.transition3.conv.weight", "features.norm5.bias", "classifier.weight"],
     "wide_resnet50_2": ["layer1.0.conv2.weight", "layer4.2.bn3.running_mean", "fc.weight"],
     "resnext50_32x4d": ["layer1.0.conv2.weight", "layer4.2.conv2.weight", "fc.bias"],
+    "shufflenet_v2_x1_0": ["conv1.0.weight", "stage2.0.branch1.0.weight", "stage2.0.branch1.2.weight",
+                           "stage3.1.branch2.3.weight", "stage4.3.branch2.6.running_var", "conv5.1.running_mean",
+                           "fc.weight"],
+    "mnasnet1_0": ["layers.0.weight", "layers.3.weight", "layers.7.running_mean", "layers.8.0.layers.3.weight",
+                   "layers.13.0.layers.6.weight", "layers.14.weight", "layers.15.bias", "classifier.1.weight"],
     "mobilenet_v2": ["features.0.0.weight", "features.1.conv.0.0.weight", "features.1.conv.1.weight",
                      "features.2.conv.1.0.weight", "features.17.conv.3.running_var", "features.18.1.running_mean",
                      "classifier.1.weight"],
@@ -59,6 +67,10 @@ def test_state_dict_names(arch):
     if arch == "resnext50_32x4d":
         assert tuple(sd["layer1.0.conv2.weight"].shape) == (128, 4, 3, 3)
         assert tuple(sd["layer4.2.conv2.weight"].shape) == (1024, 32, 3, 3)
+    if arch == "shufflenet_v2_x1_0":
+        assert tuple(sd["stage2.0.branch2.3.weight"].shape) == (58, 1, 3, 3)
+    if arch == "mnasnet1_0":
+        assert tuple(sd["layers.9.0.layers.3.weight"].shape) == (72, 1, 5, 5)
     if arch == "mobilenet_v2":
         assert tuple(sd["features.2.conv.1.0.weight"].shape) == (96, 1, 3, 3)
     if arch == "densenet121":
@@ -67,7 +79,7 @@ def test_state_dict_names(arch):
 
 @pytest.mark.parametrize("arch,size,kw", [
     ("vgg11_bn", 32, {"dropout": 0.0}), ("alexnet", 64, {}), ("squeezenet1_1", 48, {}), ("squeezenet1_0", 64, {}),
-    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {}), ("mobilenet_v2", 64, {})])
+    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {}), ("mobilenet_v2", 64, {}), ("shufflenet_v2_x1_0", 64, {}), ("mnasnet0_5", 64, {})])
 def test_one_training_step(arch, size, kw):
     torch.manual_seed(0)
     m = models.get_model(arch, num_classes=10, **kw)
@@ -103,3 +115,12 @@ def test_ceil_mode_pool_matches_torch():
                           torch.nn.functional.adaptive_avg_pool2d(a.permute(0, 3, 1, 2), 3).permute(0, 2, 3, 1),
                           atol=1e-6)
     assert ops.adaptive_avg_pool2d(a, (7, 6)) is a
+
+
+def test_channel_shuffle_matches_nchw_definition():
+    from pytorch_distributed_amd.models.shufflenet import channel_shuffle
+    x = torch.arange(2 * 3 * 3 * 12, dtype=torch.float32).reshape(2, 3, 3, 12)
+    nchw = x.permute(0, 3, 1, 2)
+    n, c, h, w = nchw.shape
+    ref = nchw.reshape(n, 2, c // 2, h, w).transpose(1, 2).reshape(n, c, h, w).permute(0, 2, 3, 1)
+    assert torch.equal(channel_shuffle(x, 2), ref)

@@ -20,13 +20,14 @@ def _cos(a, b):
 
 CASES = [("vgg11", 32, 4), ("vgg13_bn", 32, 8), ("alexnet", 96, 4), ("squeezenet1_0", 64, 4),
          ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8), ("resnext50_32x4d", 64, 8),
-         ("mobilenet_v2", 64, 8)]
+         ("mobilenet_v2", 64, 8), ("shufflenet_v2_x1_0", 64, 8), ("shufflenet_v2_x0_5", 64, 8),
+         ("mnasnet1_0", 64, 8)]
 
 
 @pytest.mark.parametrize("arch,hw,batch", CASES)
 def test_family_matches_cpu_math_fp32(arch, hw, batch):
     torch.manual_seed(5)
-    kw = {} if arch.startswith(("densenet", "wide_", "resnext")) else {"dropout": 0.0}
+    kw = {} if arch.startswith(("densenet", "wide_", "resnext", "shufflenet")) else {"dropout": 0.0}
     cpu = models.get_model(arch, num_classes=16, **kw)
     gpu = copy.deepcopy(cpu).to(DEV)
     x = torch.randn(batch, 3, hw, hw)
@@ -51,13 +52,14 @@ def test_family_matches_cpu_math_fp32(arch, hw, batch):
 
 
 @pytest.mark.parametrize("arch,hw,batch", [("vgg11_bn", 32, 8), ("squeezenet1_1", 64, 8), ("densenet121", 64, 8),
-                                           ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8), ("mobilenet_v2", 64, 8)])
+                                           ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8), ("mobilenet_v2", 64, 8),
+                                           ("shufflenet_v2_x1_0", 64, 8), ("mnasnet1_0", 64, 8)])
 def test_family_amp_step(arch, hw, batch):
     """fp16 O2 + fused SGD: finite loss, every parameter moves, a second step lowers the loss on the same batch."""
     from pytorch_distributed_amd import amp
     from pytorch_distributed_amd.optim import FusedSGD
     torch.manual_seed(6)
-    kw = {} if arch.startswith(("densenet", "resnext")) else {"dropout": 0.0}
+    kw = {} if arch.startswith(("densenet", "resnext", "shufflenet")) else {"dropout": 0.0}
     m = models.get_model(arch, num_classes=16, **kw).to(DEV)
     opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     m, opt = amp.initialize(m, opt, opt_level="O2", verbosity=0)
@@ -65,7 +67,7 @@ def test_family_amp_step(arch, hw, batch):
     t = torch.randint(0, 16, (batch,), device=DEV)
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
     losses = []
-    for _ in range(6):
+    for _ in range(16):   # the dynamic loss scale starts at 2**16: the first steps may overflow and be skipped
         opt.zero_grad()
         loss = ops.cross_entropy(m(x), t)
         with amp.scale_loss(loss, opt) as scaled:
