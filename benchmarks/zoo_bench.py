@@ -15,7 +15,7 @@ import torch
 from pytorch_distributed_amd import amp, backends, models, ops
 from pytorch_distributed_amd.optim import FusedSGD
 
-DEFAULT = "resnet18,resnet50,wide_resnet50_2,resnext50_32x4d,vgg16,vgg16_bn,alexnet,squeezenet1_1,densenet121,mobilenet_v2,shufflenet_v2_x1_0,mnasnet1_0"
+DEFAULT = "resnet18,resnet50,wide_resnet50_2,resnext50_32x4d,vgg16,vgg16_bn,alexnet,squeezenet1_1,densenet121,mobilenet_v2,shufflenet_v2_x1_0,mnasnet1_0,googlenet,inception_v3"
 
 
 def run(arch: str, batch: int, steps: int, warmup: int, size: int) -> float:

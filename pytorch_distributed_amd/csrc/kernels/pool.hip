@@ -79,6 +79,83 @@ maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__
   }
 }
 
+// Average pooling, padding counted in the divisor (torch's count_include_pad=True default): Inception's
+// 3x3 s1 p1 branch pools, the 5x5 s3 pool of its auxiliary head, DenseNet's 2x2 s2 transitions.
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo, int k,
+                   int s, int p) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * Ho * Wo * vpr;
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    long long r = i / vpr;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int a = 0; a < k; ++a) {
+      const int h = ho * s - p + a;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int w = wo * s - p + b;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const VecN<T, EPC> v = loadN<T, EPC>(x + (((long long)n * H + h) * W + w) * C + cv * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += ElemTraits<T>::to_f32(v.v[e]);
+      }
+    }
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e] * inv);
+    storeN<T, EPC>(out + i * EPC, o);
+  }
+}
+
+// One thread per input pixel-vector: the sum of the output gradients of every window that covers it.
+template <typename T, int EPC>
+__global__ void __launch_bounds__(256)
+avgpool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int k,
+                   int s, int p) {
+  const int vpr = C / EPC;
+  const long long total = (long long)N * H * W * vpr;
+  const float inv = 1.f / (float)(k * k);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % vpr);
+    long long r = i / vpr;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const long long n = r / H;
+    // windows ho with ho*s - p <= h <= ho*s - p + k - 1
+    int ho_lo = h + p - k + 1 + s - 1;
+    ho_lo = ho_lo < 0 ? 0 : ho_lo / s;
+    int ho_hi = (h + p) / s;
+    if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+    int wo_lo = w + p - k + 1 + s - 1;
+    wo_lo = wo_lo < 0 ? 0 : wo_lo / s;
+    int wo_hi = (w + p) / s;
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const VecN<T, EPC> g = loadN<T, EPC>(dout + (((n * Ho + ho) * Wo + wo) * vpr + cv) * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += ElemTraits<T>::to_f32(g.v[e]);
+      }
+    VecN<T, EPC> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e] * inv);
+    storeN<T, EPC>(dx + i * EPC, o);
+  }
+}
+
 // out[n][c] = mean over HW of x[n][hw][c]   (fp32 accumulate)
 template <typename T, int EPC>
 __global__ void __launch_bounds__(256)
@@ -161,6 +238,26 @@ PDA_EXPORT int pda_maxpool_bwd(int dtype, const void* dout, const unsigned char*
   if (total == 0) return 0;
   PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_bwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
                                            (const T*)dout, idx, (T*)dx, N, H, W, C, Ho, Wo, k, s, p));
+  return pda_check_launch();
+}
+
+// dir 0: a = x [N,H,W,C] -> b = out [N,Ho,Wo,C];  dir 1: a = dout [N,Ho,Wo,C] -> b = dx [N,H,W,C]
+PDA_EXPORT int pda_avgpool(int dtype, int dir, const void* a, void* b, int N, int H, int W, int C, int Ho, int Wo,
+                           int k, int s, int p, hipStream_t st) {
+  if (k < 1 || s < 1 || p < 0 || 2 * p > k || H + 2 * p < k || W + 2 * p < k) return -1;
+  if (Ho != (H + 2 * p - k) / s + 1 || Wo != (W + 2 * p - k) / s + 1) return -2;
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  const bool vec = (C % epc) == 0;
+  if (!vec) epc = 1;
+  const long long total = (long long)N * (dir == 0 ? (long long)Ho * Wo : (long long)H * W) * (C / epc);
+  if (total == 0) return 0;
+  if (dir == 0) {
+    PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((avgpool_fwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                             (const T*)a, (T*)b, N, H, W, C, Ho, Wo, k, s, p));
+  } else {
+    PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((avgpool_bwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
+                                             (const T*)a, (T*)b, N, H, W, C, Ho, Wo, k, s, p));
+  }
   return pda_check_launch();
 }
 

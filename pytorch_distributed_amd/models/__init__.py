@@ -17,17 +17,19 @@ from .mobilenet import MobileNetV2, mobilenet_v2
 from .shufflenet import (ShuffleNetV2, shufflenet_v2_x0_5, shufflenet_v2_x1_0, shufflenet_v2_x1_5,
                          shufflenet_v2_x2_0)
 from .mnasnet import MNASNet, mnasnet0_5, mnasnet0_75, mnasnet1_0, mnasnet1_3
+from .googlenet import GoogLeNet, googlenet
+from .inception import Inception3, inception_v3
 from .mnist import Net, mnist_net
 from .reference import torch_resnet, TorchResNet
 
-# Families built from dense, grouped and depthwise convolutions.  torchvision's mobilenet_v3* and the
-# multi-branch Inception / GoogLeNet are not provided.
+# Every classification architecture of the torchvision release the reference pins (0.4.0:
+# /root/reference/requirements.txt:2), plus resnext101_64x4d.
 model_names = sorted(["resnet18", "resnet34", "resnet50", "resnet101", "resnet152", "wide_resnet50_2",
                       "wide_resnet101_2", "resnext50_32x4d", "resnext101_32x8d", "resnext101_64x4d", "alexnet", "vgg11", "vgg11_bn", "vgg13", "vgg13_bn", "vgg16", "vgg16_bn",
                       "vgg19", "vgg19_bn", "squeezenet1_0", "squeezenet1_1", "densenet121", "densenet161",
                       "densenet169", "densenet201", "mobilenet_v2", "shufflenet_v2_x0_5", "shufflenet_v2_x1_0",
                       "shufflenet_v2_x1_5", "shufflenet_v2_x2_0", "mnasnet0_5", "mnasnet0_75", "mnasnet1_0",
-                      "mnasnet1_3", "mnist_net"])
+                      "mnasnet1_3", "googlenet", "inception_v3", "mnist_net"])
 
 
 def get_model(arch: str, pretrained: bool = False, **kw):
@@ -49,5 +51,5 @@ def load_pretrained(model, arch: str) -> None:
     model.load_state_dict(sd.get("state_dict", sd))
 
 
-__all__ = ["ResNet", "BasicBlock", "Bottleneck", "VGG", "AlexNet", "SqueezeNet", "DenseNet", "MobileNetV2", "ShuffleNetV2", "MNASNet", *model_names,
+__all__ = ["ResNet", "BasicBlock", "Bottleneck", "VGG", "AlexNet", "SqueezeNet", "DenseNet", "MobileNetV2", "ShuffleNetV2", "MNASNet", "GoogLeNet", "Inception3", *model_names,
            "Net", "mnist_net", "torch_resnet", "TorchResNet", "model_names", "get_model", "load_pretrained"]

@@ -38,6 +38,7 @@ _SIGS = {
     "pda_krsc_to_crsk_batched": [c_i, c_i, c_p, c_p, c_i, c_p],
     "pda_direct_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                         c_i, c_i, c_p],
+    "pda_avgpool": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_depthwise_conv": [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            c_i, c_i, c_p],
     "pda_bn_num_partials": [c_ll, c_i, c_i],

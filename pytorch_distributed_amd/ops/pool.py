@@ -71,11 +71,44 @@ def max_pool2d(x: torch.Tensor, k: int, s: int = None, p: int = 0, ceil_mode: bo
     return _MaxPoolFn.apply(x, k, s, p, ceil_mode)
 
 
-def avg_pool2d(x: torch.Tensor, k: int, s: int = None) -> torch.Tensor:
-    """Unpadded average pooling of an NHWC tensor (the 2x2 s2 pool of a DenseNet transition); a reshape and
-    an fp32-accumulated mean when the windows tile the input, stock pooling on a transposed view otherwise."""
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def _launch(direction, a, b, geom):
+        l = _lib.lib()
+        _lib.check(l.pda_avgpool(_lib.dt(a), direction, a.data_ptr(), b.data_ptr(), *geom, _lib.stream()),
+                   "pda_avgpool")
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x.contiguous()
+        N, H, W, Cc = x.shape
+        if not 0 <= 2 * p <= k or H + 2 * p < k or W + 2 * p < k:
+            raise ValueError(f"avg pool: window {k}, stride {s}, padding {p} do not fit a {H}x{W} input")
+        Ho, Wo = out_size(H, k, s, p), out_size(W, k, s, p)
+        out = torch.empty((N, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
+        ctx.geom = (N, H, W, Cc, Ho, Wo, k, s, p)
+        _AvgPoolFn._launch(0, x, out, ctx.geom)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        N, H, W, Cc = ctx.geom[:4]
+        dx = torch.empty((N, H, W, Cc), device=dout.device, dtype=dout.dtype)
+        _AvgPoolFn._launch(1, dout, dx, ctx.geom)
+        return dx, None, None, None
+
+
+def avg_pool2d(x: torch.Tensor, k: int, s: int = None, p: int = 0) -> torch.Tensor:
+    """Average pooling of an NHWC tensor, padding counted in the mean as ``F.avg_pool2d`` does by default
+    (Inception's 3x3 s1 p1 branch pools and 5x5 s3 auxiliary pool, DenseNet's 2x2 s2 transitions).  Own
+    kernels on the GPU: the stock op's backward on a channels-last view returned wrong gradients there."""
     s = k if s is None else s
     N, H, W, Cc = x.shape
+    if x.is_cuda:
+        return _AvgPoolFn.apply(x, k, s, p)
+    if p:
+        return F.avg_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
     if s == k:
         Ho, Wo = H // k, W // k
         if (Ho * k, Wo * k) != (H, W):
@@ -93,7 +126,9 @@ def adaptive_avg_pool2d(x: torch.Tensor, out_hw) -> torch.Tensor:
         return x
     if (oh, ow) == (1, 1):
         return global_avg_pool(x).view(N, 1, 1, Cc)
-    return F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2), (oh, ow)).permute(0, 2, 3, 1).contiguous()
+    # stock pooling, on a contiguous NCHW copy: on the GPU the stock pooling backward is not trusted with
+    # channels-last views (see avg_pool2d)
+    return F.adaptive_avg_pool2d(x.permute(0, 3, 1, 2).contiguous(), (oh, ow)).permute(0, 2, 3, 1).contiguous()
 
 
 class _GapFn(torch.autograd.Function):

@@ -13,7 +13,7 @@ PARAMS = {
     "densenet121": 7978856, "densenet161": 28681000, "densenet169": 14149480, "densenet201": 20013928,
     "wide_resnet50_2": 68883240, "wide_resnet101_2": 126886696,
     "resnext50_32x4d": 25028904, "resnext101_32x8d": 88791336, "resnext101_64x4d": 83455272,
-    "mobilenet_v2": 3504872,
+    "mobilenet_v2": 3504872, "googlenet": 6624904, "inception_v3": 23834568,
     "shufflenet_v2_x0_5": 1366792, "shufflenet_v2_x1_0": 2278604, "shufflenet_v2_x1_5": 3503624,
     "shufflenet_v2_x2_0": 7393996,
     "mnasnet0_5": 2218512, "mnasnet0_75": 3170208, "mnasnet1_0": 4383312, "mnasnet1_3": 6282256,
@@ -31,6 +31,10 @@ KEYS = {
                     "features.transition3.conv.weight", "features.norm5.bias", "classifier.weight"],
     "wide_resnet50_2": ["layer1.0.conv2.weight", "layer4.2.bn3.running_mean", "fc.weight"],
     "resnext50_32x4d": ["layer1.0.conv2.weight", "layer4.2.conv2.weight", "fc.bias"],
+    "googlenet": ["conv1.conv.weight", "inception3a.branch2.1.bn.running_mean", "inception5b.branch4.1.conv.weight",
+                  "fc.weight"],
+    "inception_v3": ["Conv2d_1a_3x3.conv.weight", "Mixed_5b.branch5x5_2.conv.weight", "Mixed_6b.branch7x7_2.conv.weight",
+                     "Mixed_7c.branch3x3dbl_3b.bn.running_var", "fc.bias"],
     "shufflenet_v2_x1_0": ["conv1.0.weight", "stage2.0.branch1.0.weight", "stage2.0.branch1.2.weight",
                            "stage3.1.branch2.3.weight", "stage4.3.branch2.6.running_var", "conv5.1.running_mean",
                            "fc.weight"],
@@ -71,6 +75,8 @@ def test_state_dict_names(arch):
         assert tuple(sd["stage2.0.branch2.3.weight"].shape) == (58, 1, 3, 3)
     if arch == "mnasnet1_0":
         assert tuple(sd["layers.9.0.layers.3.weight"].shape) == (72, 1, 5, 5)
+    if arch == "inception_v3":
+        assert tuple(sd["Mixed_6b.branch7x7_2.conv.weight"].shape) == (128, 128, 1, 7)
     if arch == "mobilenet_v2":
         assert tuple(sd["features.2.conv.1.0.weight"].shape) == (96, 1, 3, 3)
     if arch == "densenet121":
@@ -79,7 +85,7 @@ def test_state_dict_names(arch):
 
 @pytest.mark.parametrize("arch,size,kw", [
     ("vgg11_bn", 32, {"dropout": 0.0}), ("alexnet", 64, {}), ("squeezenet1_1", 48, {}), ("squeezenet1_0", 64, {}),
-    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {}), ("mobilenet_v2", 64, {}), ("shufflenet_v2_x1_0", 64, {}), ("mnasnet0_5", 64, {})])
+    ("densenet121", 32, {}), ("wide_resnet50_2", 32, {}), ("resnext50_32x4d", 32, {}), ("mobilenet_v2", 64, {}), ("shufflenet_v2_x1_0", 64, {}), ("mnasnet0_5", 64, {}), ("googlenet", 64, {}), ("inception_v3", 96, {})])
 def test_one_training_step(arch, size, kw):
     torch.manual_seed(0)
     m = models.get_model(arch, num_classes=10, **kw)
@@ -124,3 +130,21 @@ def test_channel_shuffle_matches_nchw_definition():
     n, c, h, w = nchw.shape
     ref = nchw.reshape(n, 2, c // 2, h, w).transpose(1, 2).reshape(n, c, h, w).permute(0, 2, 3, 1)
     assert torch.equal(channel_shuffle(x, 2), ref)
+
+
+def test_auxiliary_heads_match_torchvision_counts_and_outputs():
+    """With ``aux_logits=True`` (torchvision's default) the parameter counts are the published ones and
+    training mode returns the upstream named tuples; eval mode returns the logits alone."""
+    from pytorch_distributed_amd.models.googlenet import GoogLeNet, GoogLeNetOutputs
+    from pytorch_distributed_amd.models.inception import Inception3, InceptionOutputs
+    with torch.device("meta"):
+        assert sum(p.numel() for p in GoogLeNet(aux_logits=True).parameters()) == 13004888
+        assert sum(p.numel() for p in Inception3(aux_logits=True).parameters()) == 27161264
+    g = GoogLeNet(num_classes=7, aux_logits=True)
+    out = g(torch.randn(2, 3, 96, 96))
+    assert isinstance(out, GoogLeNetOutputs) and all(o.shape == (2, 7) for o in out)
+    g.eval()
+    assert g(torch.randn(2, 3, 96, 96)).shape == (2, 7)
+    i3 = Inception3(num_classes=7, aux_logits=True)
+    out = i3(torch.randn(2, 3, 299, 299))
+    assert isinstance(out, InceptionOutputs) and out.logits.shape == (2, 7) and out.aux_logits.shape == (2, 7)

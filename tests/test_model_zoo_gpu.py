@@ -21,7 +21,7 @@ def _cos(a, b):
 CASES = [("vgg11", 32, 4), ("vgg13_bn", 32, 8), ("alexnet", 96, 4), ("squeezenet1_0", 64, 4),
          ("squeezenet1_1", 47, 4), ("densenet121", 64, 8), ("wide_resnet50_2", 64, 8), ("resnext50_32x4d", 64, 8),
          ("mobilenet_v2", 64, 8), ("shufflenet_v2_x1_0", 64, 8), ("shufflenet_v2_x0_5", 64, 8),
-         ("mnasnet1_0", 64, 8)]
+         ("mnasnet1_0", 64, 8), ("googlenet", 64, 8), ("inception_v3", 160, 8)]
 
 
 @pytest.mark.parametrize("arch,hw,batch", CASES)
@@ -53,7 +53,8 @@ def test_family_matches_cpu_math_fp32(arch, hw, batch):
 
 @pytest.mark.parametrize("arch,hw,batch", [("vgg11_bn", 32, 8), ("squeezenet1_1", 64, 8), ("densenet121", 64, 8),
                                            ("alexnet", 96, 8), ("resnext50_32x4d", 64, 8), ("mobilenet_v2", 64, 8),
-                                           ("shufflenet_v2_x1_0", 64, 8), ("mnasnet1_0", 64, 8)])
+                                           ("shufflenet_v2_x1_0", 64, 8), ("mnasnet1_0", 64, 8),
+                                           ("googlenet", 64, 8), ("inception_v3", 96, 8)])
 def test_family_amp_step(arch, hw, batch):
     """fp16 O2 + fused SGD: finite loss, every parameter moves, a second step lowers the loss on the same batch."""
     from pytorch_distributed_amd import amp
@@ -179,3 +180,62 @@ def test_relu6_matches_hardtanh():
         y.backward(g)
         yr.backward(g)
         assert torch.equal(x.grad, xr.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cin,cout,ks,pad,stride", [(128, 128, (1, 7), (0, 3), 1), (160, 192, (7, 1), (3, 0), 1),
+                                                    (384, 384, (1, 3), (0, 1), 1), (48, 64, (5, 5), (2, 2), 1),
+                                                    (80, 192, (3, 3), (0, 0), 1), (3, 32, (3, 3), (0, 0), 2),
+                                                    (16, 32, (3, 3), (1, 1), 1)])
+def test_rectangular_and_padded_channel_convs(dtype, cin, cout, ks, pad, stride):
+    """Inception's factorised 1x7 / 7x1 / 1x3 filters on the implicit-GEMM kernels, and the layers whose input
+    channels are zero-padded up to the kernels' K step (3, 16, 48, 80 channels), against F.conv2d in fp32."""
+    torch.manual_seed(10)
+    x = torch.randn(4, 17, 17, cin, device=DEV, dtype=dtype, requires_grad=True)
+    w = (torch.randn(cout, cin, *ks, device=DEV) * 0.05).requires_grad_(True)
+    y = ops.conv2d(x, w, None, (stride, stride), pad)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+
+    def rel(a, r):
+        a, r = a.detach().float(), r.detach()
+        return float((a - r).norm() / (r.norm() + 1e-30))
+    assert y.shape == yr.permute(0, 2, 3, 1).shape and rel(y, yr.permute(0, 2, 3, 1)) < tol
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+    yr.backward(g.to(dtype).float())
+    assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+    assert w.grad.shape == wr.grad.shape and rel(w.grad, wr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape,k,s,p", [((8, 3, 3, 2048), 3, 1, 1), ((4, 17, 17, 288), 3, 1, 1),
+                                         ((4, 17, 17, 768), 5, 3, 0), ((4, 14, 14, 128), 2, 2, 0),
+                                         ((2, 9, 11, 20), 3, 2, 1)])
+def test_avg_pool_kernels_match_reference(dtype, shape, k, s, p):
+    """Own average-pool kernels (forward and backward) against F.avg_pool2d on the CPU in fp32."""
+    torch.manual_seed(11)
+    x = torch.randn(*shape, device=DEV, dtype=dtype, requires_grad=True)
+    xr = x.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = ops.avg_pool2d(x, k, s, p)
+    yr = F.avg_pool2d(xr, k, s, p)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    assert y.shape == yr.permute(0, 2, 3, 1).shape
+    assert torch.allclose(y.float().cpu(), yr.permute(0, 2, 3, 1), atol=tol, rtol=tol)
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(DEV, dtype).contiguous())
+    yr.backward(g.to(dtype).float())
+    assert torch.allclose(x.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1), atol=10 * tol, rtol=10 * tol)
+
+
+def test_adaptive_avg_pool_backward_gpu():
+    x = torch.randn(4, 9, 9, 64, device=DEV, requires_grad=True)
+    xr = x.detach().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y, yr = ops.adaptive_avg_pool2d(x, (4, 4)), F.adaptive_avg_pool2d(xr, (4, 4))
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(DEV).contiguous())
+    yr.backward(g)
+    assert torch.allclose(y.cpu(), yr.permute(0, 2, 3, 1), atol=1e-5)
+    assert torch.allclose(x.grad.cpu(), xr.grad.permute(0, 2, 3, 1), atol=1e-5)
