@@ -53,3 +53,20 @@ def test_style5_horovod_one_gpu(tmp_path):
     out = run(LAUNCH + ["-np", "1", "-H", "localhost:1", "--master_port", str(free_port()),
                         os.path.join(EX, "5_horovod_distributed.py")] + COMMON, tmp_path)
     assert out.count(" * Acc@1") == 2
+
+
+@pytest.mark.parametrize("arch,extra", [("mobilenet_v2", ["--graph"]), ("densenet121", []), ("shufflenet_v2_x1_0", []),
+                                        ("resnext50_32x4d", ["--graph"]), ("googlenet", [])])
+def test_other_arch_amp_ddp_one_gpu(tmp_path, arch, extra):
+    """``--arch`` beyond the ResNets through the AMP + DDP launch style (with and without hipGraph replay)."""
+    common = [a if a != "resnet18" else arch for a in COMMON]
+    out = run(LAUNCH + ["--nproc_per_node=1", "--master_port", str(free_port()), "--use_argv_local_rank",
+                        os.path.join(EX, "4_amp_distributed.py")] + common + extra + ["--opt-level", "O2"], tmp_path)
+    assert out.count(" * Acc@1") == 2
+    assert (tmp_path / f"{arch}.checkpoint.pth.tar").exists()
+
+
+def test_other_arch_dataparallel_one_gpu(tmp_path):
+    common = [a if a != "resnet18" else "squeezenet1_1" for a in COMMON]
+    out = run([sys.executable, os.path.join(EX, "1_dataparallel.py")] + common, tmp_path)
+    assert out.count(" * Acc@1") == 2
