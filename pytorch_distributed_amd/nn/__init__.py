@@ -117,8 +117,10 @@ class ConvBnAct(tnn.Module):
             dout_premasked: bool = False, in_link=None, out_link=None):
         """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
+        pointwise = conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
         if conv.bias is not None or conv.groups != 1 or conv.out_channels % 8 \
-                or not _conv.igemm_tiles(conv.in_channels, x.dtype):
+                or not _conv.igemm_tiles(conv.in_channels, x.dtype) \
+                or not (pointwise or _conv.igemm_tiles(conv.out_channels, x.dtype)):
             # unfused modules (a bias, groups, or a channel count the MFMA kernels do not tile): the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
             # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
             # gradient mask on x

@@ -470,21 +470,26 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
     if not x.is_cuda:
         return conv2d_ref(x, weight, bias, stride, pad)
     K, Cin, R, S = weight.shape
-    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) \
-            and (K % 8 != 0 or not igemm_tiles(Cin, x.dtype)):
+    # the implicit-GEMM kernels step through 64 bytes of channels: the input channels in fprop / wgrad, the
+    # output channels in dgrad
+    tiled_in, tiled_out = igemm_tiles(Cin, x.dtype), igemm_tiles(K, x.dtype)
+    if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not (tiled_in and tiled_out):
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
-        # do not tile (24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
+        # do not tile (16, 24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
         return F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
-    if K % 8 == 0 and not igemm_tiles(Cin, x.dtype):
-        # an image (3 channels) or a narrow feature map (16, 48 channels in 16-bit): zero-pad the channels of
-        # the activation and of the filter up to the kernels' K step and run on the matrix cores - the padded
-        # FLOPs are cheaper than the scalar fallback by orders of magnitude (the padding is differentiable: the
-        # gradients of the real channels come back through the slice).  A fresh cache: the padded filter is a
-        # temporary, nothing about it may be remembered across calls.
+    if K % 8 == 0 and not (tiled_in and (tiled_out or not x.requires_grad)):
+        # an image (3 channels), a narrow feature map (16, 48 channels in 16-bit) or an odd filter count (208):
+        # zero-pad the channels of the activation and of the filter up to the kernels' step and run on the
+        # matrix cores - the padded FLOPs are cheaper than the scalar fallback by orders of magnitude (the
+        # padding is differentiable: the gradients of the real channels come back through the slices).  A
+        # fresh cache: the padded filter is a temporary, nothing about it may be remembered across calls.
         step = 64 // x.element_size()
-        extra = -Cin % step
-        return _Conv2dFn.apply(F.pad(x, (0, extra)), F.pad(weight, (0, 0, 0, 0, 0, extra)), bias, tuple(stride),
-                               tuple(pad), WeightCache())
+        ec = -Cin % step
+        ek = -K % step if x.requires_grad else 0
+        y = _Conv2dFn.apply(F.pad(x, (0, ec)) if ec else x, F.pad(weight, (0, 0, 0, 0, 0, ec, 0, ek)),
+                            F.pad(bias, (0, ek)) if (bias is not None and ek) else bias, tuple(stride), tuple(pad),
+                            WeightCache())
+        return y[..., :K].contiguous() if ek else y
     return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())
 
 

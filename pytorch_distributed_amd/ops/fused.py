@@ -150,9 +150,16 @@ class _ConvBnActFn(torch.autograd.Function):
                             res=dalias, mask=x if mask_x else None, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
                             bn_sums=bn_in is not None)
             if r is None:
-                dx = torch.empty_like(x)
-                C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
-                              (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S), stride, pad)
+                if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
+                    # pointwise conv with a filter count the dgrad kernel does not step through (16, 24 in
+                    # MobileNet): dX = dY [pixels, K] x W [K, Cin] on the library GEMM
+                    dx = torch.matmul(dy.reshape(-1, K), cache.low_precision(weight, dy.dtype).reshape(K, Cin))
+                    dx = dx.view(x.shape)
+                else:
+                    dx = torch.empty_like(x)
+                    C.direct_conv(1, dy, cache.low_precision(weight, dy.dtype), None, dx,
+                                  (x.shape[0], x.shape[1], x.shape[2], Cin, dy.shape[1], dy.shape[2], K, R, S),
+                                  stride, pad)
                 if dalias is not None:
                     dx = dx + dalias
                 if mask_x or sc is not None:
