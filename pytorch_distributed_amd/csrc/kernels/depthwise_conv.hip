@@ -143,6 +143,68 @@ dw_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __rest
     }
 }
 
+// Same decomposition, a whole filter row per pass: the S taps of row r share one load of dy and sit in
+// registers (S x EPC accumulators), so dy is read R times instead of R*S times (3x3 and 5x5 filters).
+template <typename T, int EPC, int SW>
+__global__ void __launch_bounds__(256)
+dw_wgrad_row_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw, DwGeom g,
+                    long long slab, int use_atomic) {
+  __shared__ float red[DW_PXL][DW_CVB * EPC + 1];
+  const int vpr = g.C / EPC;
+  const int tx = threadIdx.x % DW_CVB, ty = threadIdx.x / DW_CVB;
+  const int cv = blockIdx.x * DW_CVB + tx;
+  const bool live = cv < vpr;
+  const long long M = (long long)g.N * g.Ho * g.Wo;
+  const long long m0 = (long long)blockIdx.y * slab;
+  const long long m1 = m0 + slab < M ? m0 + slab : M;
+  for (int r = 0; r < g.R; ++r) {
+    float acc[SW][EPC];
+#pragma unroll
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[s][e] = 0.f;
+    if (live) {
+      for (long long m = m0 + ty; m < m1; m += DW_PXL) {
+        const int wo = (int)(m % g.Wo);
+        const long long q = m / g.Wo;
+        const int ho = (int)(q % g.Ho);
+        const long long n = q / g.Ho;
+        const int hi = ho * g.sh - g.ph + r;
+        if ((unsigned)hi >= (unsigned)g.Hi) continue;
+        const VecN<T, EPC> gv = loadN<T, EPC>(dy + m * g.C + cv * EPC);
+        const T* xrow = x + ((n * g.Hi + hi) * g.Wi) * g.C + cv * EPC;
+        const int wi0 = wo * g.sw - g.pw;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+          const int wi = wi0 + s;
+          if ((unsigned)wi >= (unsigned)g.Wi) continue;
+          const VecN<T, EPC> xv = loadN<T, EPC>(xrow + (long long)wi * g.C);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) acc[s][e] += ElemTraits<T>::to_f32(gv.v[e]) * ElemTraits<T>::to_f32(xv.v[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) red[ty][tx * EPC + e] = acc[s][e];
+      __syncthreads();
+      if (threadIdx.x < DW_CVB * EPC) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < DW_PXL; ++p) t += red[p][threadIdx.x];
+        const int c = blockIdx.x * DW_CVB * EPC + threadIdx.x;
+        if (c < g.C) {
+          float* dst = dw + (long long)(r * SW + s) * g.C + c;
+          if (use_atomic) atomicAdd(dst, t);
+          else *dst += t;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 static inline int dw_blocks(long long n) {
   long long b = (n + 255) / 256;
   if (b > 16384) b = 16384;
@@ -198,8 +260,16 @@ PDA_EXPORT int pda_depthwise_conv(int dtype, int mode, const void* a, const void
     const long long slab = (M + ns - 1) / ns;
     const unsigned gy = (unsigned)((M + slab - 1) / slab);
     const int use_atomic = gy > 1;
-    DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_kernel<T, EPC>), dim3(gx, gy), dim3(256), 0, st,
-                                               (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
+    if (S == 3) {
+      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 3>), dim3(gx, gy), dim3(256), 0, st,
+                                                 (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
+    } else if (S == 5) {
+      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 5>), dim3(gx, gy), dim3(256), 0, st,
+                                                 (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
+    } else {
+      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_kernel<T, EPC>), dim3(gx, gy), dim3(256), 0, st,
+                                                 (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
+    }
   } else {
     return -3;
   }

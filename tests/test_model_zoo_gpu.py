@@ -131,7 +131,8 @@ def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("ch,k,stride,pad,hw,bias", [(96, 3, 1, 1, 14, False), (144, 3, 2, 1, 15, False),
-                                                    (32, 5, 2, 2, 12, True), (20, 3, 1, 1, 9, False)])
+                                                    (32, 5, 2, 2, 12, True), (20, 3, 1, 1, 9, False),
+                                                    (40, 7, 1, 3, 10, False)])
 def test_depthwise_conv_matches_reference(dtype, ch, k, stride, pad, hw, bias):
     """Depthwise kernels (vector path for channel counts that fill 16-byte vectors, scalar otherwise)
     == F.conv2d(groups=C) in fp32; also the single-slab (deterministic) weight gradient."""
