@@ -34,7 +34,8 @@ class NHWCModel(tnn.Module):
 
 def run_layers(layers, x: torch.Tensor) -> torch.Tensor:
     """``nn.Sequential`` semantics with one peephole: ``Conv2d, BatchNorm2d[, ReLU]`` runs as the fused
-    conv + BatchNorm (+ ReLU) op and ``BatchNorm2d, ReLU`` as one normalise-and-activate pass."""
+    conv + BatchNorm (+ ReLU) op, ``BatchNorm2d, ReLU`` as one normalise-and-activate pass and
+    ``Conv2d, ReLU`` with the activation inside the conv's bias pass."""
     mods = list(layers)
     i, n = 0, len(mods)
     while i < n:
@@ -46,6 +47,9 @@ def run_layers(layers, x: torch.Tensor) -> torch.Tensor:
             i += 3 if relu else 2
         elif isinstance(m, pnn.BatchNorm2d) and isinstance(nxt, pnn.ReLU):
             x = m(x, None, True)
+            i += 2
+        elif isinstance(m, pnn.Conv2d) and isinstance(nxt, pnn.ReLU) and not m._forward_hooks:
+            x = m(x, relu=True)   # the activation rides in the conv's bias pass
             i += 2
         else:
             x = m(x)

@@ -27,7 +27,7 @@ class Fire(tnn.Module):
         self.expand3x3_activation = pnn.ReLU()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = ops.relu(self.squeeze(x))
+        x = self.squeeze(x, relu=True)
         # relu(cat(a, b)) == cat(relu(a), relu(b)): one activation pass over the joined tensor
         return ops.relu(torch.cat([self.expand1x1(x), self.expand3x3(x)], dim=3))
 

@@ -42,8 +42,8 @@ class Conv2d(tnn.Module):
             bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
             tnn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache, self.groups)
+    def forward(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self._cache, self.groups, relu)
 
     def extra_repr(self) -> str:
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "

@@ -395,10 +395,10 @@ def _refresh_transposes(dtype: torch.dtype, device) -> None:
 
 # --------------------------------------------------------------------------- autograd op
 class _Conv2dFn(torch.autograd.Function):
-    """Plain convolution (optional bias) on the GPU kernels."""
+    """Plain convolution (optional bias, optional ReLU applied in the bias pass) on the GPU kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, cache: WeightCache):
+    def forward(ctx, x, weight, bias, stride, pad, cache: WeightCache, relu: bool = False):
         x = x.contiguous()
         dtype = x.dtype
         K, C, R, S = weight.shape
@@ -411,20 +411,31 @@ class _Conv2dFn(torch.autograd.Function):
             y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=dtype)
             direct_conv(0, x, w_lp, bias.float() if bias is not None else None, y,
                         (N, Hi, Wi, C, Ho, Wo, K, R, S), stride, pad)
+            if relu:
+                _lib.check(_lib.lib().pda_relu_fwd(_lib.dt(y), y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream()),
+                           "pda_relu_fwd")
         elif bias is not None:
             l = _lib.lib()
             _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), K,
-                                      0, _lib.stream()), "pda_bias_add")
-        ctx.save_for_backward(x, weight)
+                                      int(relu), _lib.stream()), "pda_bias_add")
+        elif relu:
+            _lib.check(_lib.lib().pda_relu_fwd(_lib.dt(y), y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream()),
+                       "pda_relu_fwd")
+        ctx.save_for_backward(x, weight, y if relu else None)
         ctx.w_lp = w_lp
         ctx.cfg = (stride, pad, cache, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, y_act = ctx.saved_tensors
         stride, pad, cache, has_bias = ctx.cfg
         dy = dy.contiguous()
+        if y_act is not None:   # the ReLU that ran in the bias pass
+            masked = torch.empty_like(dy)
+            _lib.check(_lib.lib().pda_relu_bwd(_lib.dt(dy), dy.data_ptr(), y_act.data_ptr(), masked.data_ptr(),
+                                               dy.numel(), _lib.stream()), "pda_relu_bwd")
+            dy = masked
         K, C, R, S = weight.shape
         N, Hi, Wi, _ = x.shape
         Ho, Wo = dy.shape[1], dy.shape[2]
@@ -451,7 +462,7 @@ class _Conv2dFn(torch.autograd.Function):
             _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), N * Ho * Wo, K,
                                     int(backends.deterministic), _lib.stream()),
                        "pda_colsum")
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def conv2d_ref(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad) -> torch.Tensor:
@@ -462,8 +473,12 @@ def conv2d_ref(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad) -> torc
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=(0, 0),
-           cache: Optional[WeightCache] = None, groups: int = 1) -> torch.Tensor:
-    """NHWC convolution. ``weight`` is logical [K,C/groups,R,S]."""
+           cache: Optional[WeightCache] = None, groups: int = 1, relu: bool = False) -> torch.Tensor:
+    """NHWC convolution (+ ReLU with ``relu=True``: on the dense GPU path it rides in the bias pass).
+    ``weight`` is logical [K,C/groups,R,S]."""
+    if relu and (groups != 1 or not x.is_cuda):
+        from .elementwise import relu as _relu
+        return _relu(conv2d(x, weight, bias, stride, pad, cache, groups))
     if groups != 1:
         from .grouped import grouped_conv2d
         return grouped_conv2d(x, weight, bias, stride, pad, groups)
@@ -476,7 +491,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
     if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not (tiled_in and tiled_out):
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
         # do not tile (16, 24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
-        return F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
+        y = F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
+        if relu:
+            from .elementwise import relu as _relu
+            y = _relu(y)
+        return y
     if K % 8 == 0 and not (tiled_in and (tiled_out or not x.requires_grad)):
         # an image (3 channels), a narrow feature map (16, 48 channels in 16-bit) or an odd filter count (208):
         # zero-pad the channels of the activation and of the filter up to the kernels' step and run on the
@@ -488,9 +507,9 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
         ek = -K % step if x.requires_grad else 0
         y = _Conv2dFn.apply(F.pad(x, (0, ec)) if ec else x, F.pad(weight, (0, 0, 0, 0, 0, ec, 0, ek)),
                             F.pad(bias, (0, ek)) if (bias is not None and ek) else bias, tuple(stride), tuple(pad),
-                            WeightCache())
+                            WeightCache(), relu)
         return y[..., :K].contiguous() if ek else y
-    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache())
+    return _Conv2dFn.apply(x, weight, bias, tuple(stride), tuple(pad), cache or WeightCache(), relu)
 
 
 def igemm_tiles(channels: int, dtype: torch.dtype) -> bool:
