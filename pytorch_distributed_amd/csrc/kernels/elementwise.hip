@@ -38,32 +38,44 @@ nchw_to_nhwc_kernel(const TI* __restrict__ in, TO* __restrict__ out, int N, int 
   }
 }
 
+// ReLU and its clipped form (ReLU6): y = min(max(x, 0), cap), cap = +inf for the plain one; the gradient
+// passes where 0 < y < cap (torch.nn.functional.hardtanh's rule at the upper end).  One 16-byte vector per
+// lane; the last n % (16 / sizeof(T)) elements are handled one by one by the first lanes.
 template <typename T>
 __global__ void __launch_bounds__(256)
-relu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    y[i] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(x[i]), 0.f));
-}
-template <typename T>
-__global__ void __launch_bounds__(256)
-relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    dx[i] = ElemTraits<T>::to_f32(y[i]) > 0.f ? dy[i] : ElemTraits<T>::from_f32(0.f);
-}
-// ReLU6-style clipped activation: y = min(max(x, 0), cap); gradient passes where 0 < y < cap
-// (torch.nn.functional.hardtanh's rule: nothing at the two ends).
-template <typename T>
-__global__ void __launch_bounds__(256)
-relu_cap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float cap) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+relu_cap_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float cap, int vec) {
+  constexpr int EPC = Vec16<T>::N;
+  const long long nvec = vec ? n / EPC : 0;   // vec == 0: a pointer is not 16-byte aligned
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+  for (long long i = tid; i < nvec; i += nthr) {
+    Vec16<T> v = load16(x + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.v[e] = ElemTraits<T>::from_f32(fminf(fmaxf(ElemTraits<T>::to_f32(v.v[e]), 0.f), cap));
+    store16(y + i * EPC, v);
+  }
+  for (long long i = nvec * EPC + tid; i < n; i += nthr)
     y[i] = ElemTraits<T>::from_f32(fminf(fmaxf(ElemTraits<T>::to_f32(x[i]), 0.f), cap));
 }
 template <typename T>
 __global__ void __launch_bounds__(256)
-relu_cap_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n, float cap) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float v = ElemTraits<T>::to_f32(y[i]);
-    dx[i] = (v > 0.f && v < cap) ? dy[i] : ElemTraits<T>::from_f32(0.f);
+relu_cap_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long long n, float cap,
+                    int vec) {
+  constexpr int EPC = Vec16<T>::N;
+  const long long nvec = vec ? n / EPC : 0;
+  const long long tid = blockIdx.x * (long long)blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+  for (long long i = tid; i < nvec; i += nthr) {
+    Vec16<T> g = load16(dy + i * EPC);
+    const Vec16<T> v = load16(y + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float f = ElemTraits<T>::to_f32(v.v[e]);
+      if (!(f > 0.f && f < cap)) g.v[e] = ElemTraits<T>::from_f32(0.f);
+    }
+    store16(dx + i * EPC, g);
+  }
+  for (long long i = nvec * EPC + tid; i < n; i += nthr) {
+    const float f = ElemTraits<T>::to_f32(y[i]);
+    dx[i] = (f > 0.f && f < cap) ? dy[i] : ElemTraits<T>::from_f32(0.f);
   }
 }
 template <typename T>
@@ -218,26 +230,27 @@ PDA_EXPORT int pda_nchw_to_nhwc(int dt_in, int dt_out, const void* in, void* out
   return pda_check_launch();
 }
 
-PDA_EXPORT int pda_relu_fwd(int dtype, const void* x, void* y, long long n, hipStream_t st) {
-  if (n == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n));
-  return pda_check_launch();
-}
-PDA_EXPORT int pda_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, hipStream_t st) {
-  if (n == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n));
-  return pda_check_launch();
+static inline bool ew_aligned16(const void* a, const void* b, const void* c) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 PDA_EXPORT int pda_relu_cap_fwd(int dtype, const void* x, void* y, long long n, float cap, hipStream_t st) {
   if (n == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n, cap));
+  const int vec = ew_aligned16(x, y, nullptr);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_fwd_kernel<T>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const T*)x, (T*)y, n, cap, vec));
   return pda_check_launch();
 }
 PDA_EXPORT int pda_relu_cap_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, float cap,
                                 hipStream_t st) {
   if (n == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n, cap));
+  const int vec = ew_aligned16(dy, y, dx);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((relu_cap_bwd_kernel<T>), dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, (const T*)dy, (const T*)y, (T*)dx, n, cap, vec));
   return pda_check_launch();
+}
+PDA_EXPORT int pda_relu_fwd(int dtype, const void* x, void* y, long long n, hipStream_t st) {
+  return pda_relu_cap_fwd(dtype, x, y, n, INFINITY, st);
+}
+PDA_EXPORT int pda_relu_bwd(int dtype, const void* dy, const void* y, void* dx, long long n, hipStream_t st) {
+  return pda_relu_cap_bwd(dtype, dy, y, dx, n, INFINITY, st);
 }
 // srcs: array of nsrc (<= 8) device pointers, all 16-byte aligned like out; out may alias srcs[0].
 PDA_EXPORT int pda_add_n(int dtype, const void* const* srcs, int nsrc, void* out, long long count, hipStream_t st) {

@@ -240,3 +240,19 @@ def test_adaptive_avg_pool_backward_gpu():
     yr.backward(g)
     assert torch.allclose(y.cpu(), yr.permute(0, 2, 3, 1), atol=1e-5)
     assert torch.allclose(x.grad.cpu(), xr.grad.permute(0, 2, 3, 1), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,offset", [(1, 0), (7, 0), (4099, 0), (1 << 20, 0), (4099, 1), (65536, 3)])
+def test_relu_kernels_any_length_and_alignment(dtype, n, offset):
+    """Vector body + scalar tail, and the all-scalar path for a view that is not 16-byte aligned."""
+    base = (torch.randn(n + offset, device=DEV) * 4).to(dtype)
+    for fn, ref in ((ops.relu, torch.relu), (ops.relu6, lambda t: F.hardtanh(t, 0.0, 6.0))):
+        x = base[offset:].detach().requires_grad_(True)
+        xr = base[offset:].detach().clone().requires_grad_(True)
+        y, yr = fn(x), ref(xr)
+        assert torch.equal(y, yr)
+        g = torch.randn_like(y)
+        y.backward(g)
+        yr.backward(g)
+        assert torch.equal(x.grad, xr.grad)
