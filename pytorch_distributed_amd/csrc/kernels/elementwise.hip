@@ -134,6 +134,26 @@ bias_add_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __re
     y[i] = ElemTraits<T>::from_f32(v);
   }
 }
+// C a multiple of the 16-byte vector and 16-byte aligned pointers: one vector per lane, its channel offset
+// from a 32-bit remainder (vectors per row = C / EPC)
+template <typename T>
+__global__ void __launch_bounds__(256)
+bias_add_vec_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, long long nvec,
+                    int vpr, int relu) {
+  constexpr int EPC = Vec16<T>::N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % vpr) * EPC;
+    Vec16<T> v = load16(x + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float f = ElemTraits<T>::to_f32(v.v[e]) + bias[c0 + e];
+      if (relu) f = fmaxf(f, 0.f);
+      v.v[e] = ElemTraits<T>::from_f32(f);
+    }
+    store16(y + i * EPC, v);
+  }
+}
 // dbias[c] = sum over rows of dy[m][c]   (any C; grid.x = 64-channel groups, grid.y = row slabs).
 // One slab: plain store.  Several slabs (a first-layer conv has millions of rows and 64 channels - one
 // workgroup per 64 channels would leave the chip idle): float atomics into the zero-filled output.
@@ -278,6 +298,12 @@ PDA_EXPORT int pda_add(int dtype, const void* a, const void* b, void* o, long lo
 PDA_EXPORT int pda_bias_add(int dtype, const void* x, const float* bias, void* y, long long n, int C, int relu,
                             hipStream_t st) {
   if (n == 0) return 0;
+  const int epc = dtype == PDA_F32 ? 4 : 8;
+  if (C % epc == 0 && n % C == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const long long nvec = n / epc;
+    PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bias_add_vec_kernel<T>), dim3(ew_blocks(nvec)), dim3(256), 0, st, (const T*)x, bias, (T*)y, nvec, C / epc, relu));
+    return pda_check_launch();
+  }
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bias_add_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, C, relu));
   return pda_check_launch();
 }
