@@ -107,6 +107,21 @@ class SyncBatchNorm(BatchNorm2d):
         return module
 
 
+class _ZeroGradFor(torch.autograd.Function):
+    """Identity on ``out`` that also hands ``param`` an all-zero gradient (so that optimizers and gradient
+    reducers see every parameter of the step)."""
+
+    @staticmethod
+    def forward(ctx, out, param):
+        ctx.meta = (param.shape, param.dtype, param.device)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, dtype, device = ctx.meta
+        return dout, torch.zeros(shape, dtype=dtype, device=device)
+
+
 class ConvBnAct(tnn.Module):
     """Functional fusion helper: runs ``conv`` + ``bn`` (+ residual) (+ ReLU) as one op while the two
     sub-modules keep owning their parameters (so names stay ``conv1.weight`` / ``bn1.weight``)."""
@@ -118,6 +133,19 @@ class ConvBnAct(tnn.Module):
         """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
         pointwise = conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+        plain = not (passthrough or mask_dx or dout_premasked or in_link is not None or out_link is not None)
+        if (conv.bias is not None and plain and x.is_cuda and bn.training and bn.track_running_stats
+                and bn.momentum is not None and conv.groups == 1 and conv.out_channels % 8 == 0
+                and _conv.igemm_tiles(conv.in_channels, x.dtype)
+                and (pointwise or _conv.igemm_tiles(conv.out_channels, x.dtype))):
+            # A bias in front of a training-mode BatchNorm only moves the batch mean, which the normalisation
+            # removes again: the output is that of the bias-free fused op, the bias gradient is exactly zero,
+            # and the one place the bias shows is the running mean (VGG-*_bn keeps such biases).
+            o = ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
+                                bn.state(), conv._cache)
+            with torch.no_grad():
+                bn.running_mean.add_(conv.bias.detach().to(bn.running_mean.dtype), alpha=bn.momentum)
+            return _ZeroGradFor.apply(o, conv.bias)
         if conv.bias is not None or conv.groups != 1 or conv.out_channels % 8 \
                 or not _conv.igemm_tiles(conv.in_channels, x.dtype) \
                 or not (pointwise or _conv.igemm_tiles(conv.out_channels, x.dtype)):

@@ -77,8 +77,10 @@ def test_family_amp_step(arch, hw, batch):
         losses.append(loss.item())
     assert all(l == l and abs(l) != float("inf") for l in losses), losses
     assert losses[-1] < losses[0], losses
-    moved = [k for k, p in m.named_parameters() if not torch.equal(p.detach(), before[k])]
-    assert len(moved) == len(before), set(before) - set(moved)
+    # (a zero-initialised conv bias in front of a training-mode BatchNorm has an exactly-zero gradient)
+    still = [k for k, p in m.named_parameters() if torch.equal(p.detach(), before[k])
+             and not (p.grad is not None and float(p.grad.abs().max()) == 0.0 and float(p.detach().abs().max()) == 0.0)]
+    assert not still, still
 
 
 def test_ceil_mode_and_avg_pools_gpu():
@@ -256,3 +258,33 @@ def test_relu_kernels_any_length_and_alignment(dtype, n, offset):
         y.backward(g)
         yr.backward(g)
         assert torch.equal(x.grad, xr.grad)
+
+
+def test_conv_bias_in_front_of_training_batchnorm_is_folded():
+    """VGG-*_bn: conv(bias) + BatchNorm in training mode runs as the bias-free fused op; outputs, gradients
+    and EVERY running statistic equal the stock computation, the bias gradient is zero."""
+    torch.manual_seed(12)
+    cpu = models.get_model("vgg11_bn", num_classes=16, dropout=0.0)
+    for m in cpu.modules():   # non-trivial biases and statistics
+        if hasattr(m, "kernel_size") and getattr(m, "bias", None) is not None and m.bias.dim() == 1:
+            torch.nn.init.normal_(m.bias, 0, 0.5)
+    gpu = copy.deepcopy(cpu).to(DEV)
+    x = torch.randn(8, 3, 32, 32)
+    t = torch.randint(0, 16, (8,))
+    for _ in range(2):
+        lc = F.cross_entropy(cpu(x), t)
+        lg = ops.cross_entropy(gpu(x.to(DEV)), t.to(DEV))
+        assert abs(lc.item() - lg.item()) < 2e-3 * abs(lc.item())
+    lc.backward()
+    lg.backward()
+    for (k, bc), (_, bg) in zip(cpu.named_buffers(), gpu.named_buffers()):
+        if bc.dtype.is_floating_point:
+            assert torch.allclose(bg.cpu(), bc, rtol=2e-3, atol=2e-4), k
+    gc, gg = dict(cpu.named_parameters()), dict(gpu.named_parameters())
+    # (features.0 reads the 3-channel image and stays on the unfused path; features.4 is folded)
+    assert float(gg["features.4.bias"].grad.abs().max()) == 0.0
+    assert float(gc["features.4.bias"].grad.abs().max()) < 1e-4     # the stock gradient is rounding noise
+    assert _cos(gg["features.4.weight"].grad, gc["features.4.weight"].grad) > 0.999
+    gpu.eval(); cpu.eval()
+    with torch.no_grad():
+        assert torch.allclose(gpu(x.to(DEV)).cpu(), cpu(x), rtol=1e-2, atol=1e-3)
