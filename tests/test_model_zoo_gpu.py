@@ -288,3 +288,27 @@ def test_conv_bias_in_front_of_training_batchnorm_is_folded():
     gpu.eval(); cpu.eval()
     with torch.no_grad():
         assert torch.allclose(gpu(x.to(DEV)).cpu(), cpu(x), rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("arch", [a for a in models.model_names if a != "mnist_net"])
+def test_every_arch_one_amp_step_gpu(arch):
+    """Every registered architecture runs two fp16 O2 training steps on the HIP ops (finite loss, a gradient
+    for every parameter) - channel counts, group counts and window shapes differ a lot between the variants."""
+    from pytorch_distributed_amd import amp
+    from pytorch_distributed_amd.optim import FusedSGD
+    torch.manual_seed(13)
+    size = 96 if arch in ("alexnet", "inception_v3") else 64
+    m = models.get_model(arch, num_classes=8).to(DEV)
+    opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9)
+    m, opt = amp.initialize(m, opt, opt_level="O2", loss_scale=128.0, verbosity=0)
+    x = torch.randn(4, 3, size, size, device=DEV)
+    t = torch.randint(0, 8, (4,), device=DEV)
+    for _ in range(2):
+        opt.zero_grad()
+        loss = ops.cross_entropy(m(x), t)
+        with amp.scale_loss(loss, opt) as scaled:
+            scaled.backward()
+        missing = [k for k, p in m.named_parameters() if p.grad is None]
+        assert not missing, missing[:5]
+        opt.step()
+    assert torch.isfinite(loss).item(), loss
