@@ -465,6 +465,44 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _PointwiseGemmFn(torch.autograd.Function):
+    """1x1 stride-1 convolution whose channel counts the implicit-GEMM fprop / dgrad kernels do not step
+    through: forward and input gradient are plain ``[pixels, C] x [C, K]`` products on the library GEMM.  The
+    weight gradient is not: its output is a tiny ``[K, C]`` matrix reduced over millions of pixels, a shape the
+    library runs on a handful of workgroups - the split-K wgrad kernel of this package takes it (it only needs
+    channel counts that fill 16-byte vectors)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K, Cin = weight.shape[0], weight.shape[1]
+        w_lp = weight.detach().reshape(K, Cin).to(x.dtype)
+        y = F.linear(x, w_lp, None if bias is None else bias.detach().to(x.dtype))
+        ctx.save_for_backward(x, w_lp)
+        ctx.meta = (weight.dtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_lp = ctx.saved_tensors
+        wdtype, has_bias = ctx.meta
+        K, Cin = w_lp.shape
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(dy.reshape(-1, K), w_lp).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            vec = 16 // x.element_size()
+            d = wgrad_gpu(dy, x.contiguous(), 1, 1, (1, 1), (0, 0)) if (K % vec == 0 and Cin % vec == 0) else None
+            if d is None:
+                d = torch.matmul(dy.reshape(-1, K).t(), x.reshape(-1, Cin)).float()
+            dw = d.reshape(K, Cin, 1, 1).to(wdtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(K, device=dy.device, dtype=torch.float32)
+            _lib.check(_lib.lib().pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // K, K,
+                                             int(backends.deterministic), _lib.stream()), "pda_colsum")
+        return dx, dw, db
+
+
 def conv2d_ref(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad) -> torch.Tensor:
     """CPU / reference path: NHWC in, NHWC out, stock PyTorch math."""
     y = F.conv2d(x.permute(0, 3, 1, 2), weight.to(x.dtype), None if bias is None else bias.to(x.dtype),
@@ -491,7 +529,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
     if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not (tiled_in and tiled_out):
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
         # do not tile (16, 24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
-        y = F.linear(x, weight.reshape(K, Cin).to(x.dtype), None if bias is None else bias.to(x.dtype))
+        y = _PointwiseGemmFn.apply(x, weight, bias)
         if relu:
             from .elementwise import relu as _relu
             y = _relu(y)
