@@ -312,3 +312,34 @@ def test_every_arch_one_amp_step_gpu(arch):
         assert not missing, missing[:5]
         opt.step()
     assert torch.isfinite(loss).item(), loss
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("relu", [False, True])
+def test_filter_count_padding_with_bias_and_relu(dtype, relu):
+    """3x3 conv with a filter count the dgrad kernel does not step through (48, 208): the filter, the bias and
+    the output are zero-padded and sliced back; bias gradient and the fused ReLU included."""
+    torch.manual_seed(14)
+    for cin, cout in ((64, 48), (96, 208)):
+        x = torch.randn(4, 9, 9, cin, device=DEV, dtype=dtype, requires_grad=True)
+        w = (torch.randn(cout, cin, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+        b = torch.randn(cout, device=DEV, requires_grad=True)
+        y = ops.conv2d(x, w, b, (1, 1), (1, 1), relu=relu)
+        xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+        wr = w.detach().to(dtype).float().requires_grad_(True)
+        br = b.detach().clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, padding=1)
+        if relu:
+            # mask from the device result: a pre-activation within rounding of zero may land on either side
+            yr = yr * (y.detach().float().permute(0, 3, 1, 2) > 0)
+        tol = 1e-4 if dtype == torch.float32 else 1e-2
+
+        def rel(a, r):
+            a, r = a.detach().float(), r.detach()
+            return float((a - r).norm() / (r.norm() + 1e-30))
+        assert y.shape == (4, 9, 9, cout) and rel(y, yr.permute(0, 2, 3, 1)) < tol
+        g = torch.randn_like(yr)
+        y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+        yr.backward(g.to(dtype).float())
+        assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+        assert rel(w.grad, wr.grad) < tol and rel(b.grad, br.grad) < tol
