@@ -1,31 +1,43 @@
 #!/usr/bin/env python
 """Headline benchmark: ResNet-50 training throughput (images/sec, whole job) on
 synthetic ImageNet-shaped data, AMP fp16 with dynamic loss scaling, bucketed-all-reduce
-DDP over RCCL when launched on more than one GPU.
+DDP over RCCL when run on more than one GPU.
 
     python bench.py --gpus 1 --steps 30 --warmup 10
+    python bench.py --gpus 8 --steps 30 --warmup 10          # starts its own 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 30 --warmup 10
+        --master-port 29500 bench.py --gpus 8 --steps 30 --warmup 10   # or under any launcher
 
-One timed step = zero_grad + forward + loss + scaled backward (+ gradient all-reduce
-overlapped with backward) + overflow check + fused momentum-SGD update of all
-25.6 M parameters.  Weak scaling: the per-GPU batch is fixed.
-Rank 0 prints ONE JSON line.
+Launch: with ``--gpus N`` > 1 and no launcher environment (no ``WORLD_SIZE``), this process becomes a
+supervisor that never touches a GPU: it starts N ranks through this package's launcher
+(``python -m pytorch_distributed_amd.launch``, the way /root/reference/3.multiprocessing_distributed.py:80-84
+spawns its own workers), relays rank 0's JSON line and exits with the first failing rank's code.  If the
+ranks fail or stall on this package's own RCCL communicator, the supervisor runs them once more on
+``torch.distributed``'s process group and says so in ``comm_backend``.  Under an external launcher the
+ranks come from its environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Either way a rank
+count that differs from ``--gpus`` is an error, not a silently smaller job.
+
+One timed step = zero_grad + forward + loss + scaled backward (+ gradient all-reduce overlapped with
+backward) + overflow check + fused momentum-SGD update of all 25.6 M parameters.  Weak scaling: the
+per-GPU batch is fixed.  Rank 0 prints ONE JSON line.  Every blocking stage (rendezvous, communicator
+creation, first collective, warm-up, timed loop) runs under a deadline: a stage that exceeds it prints a
+JSON ``{"error": ...}`` line and ends the process instead of hanging.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
-import torch
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -41,47 +53,219 @@ def parse():
     ap.add_argument("--engine", default="native", choices=["native", "stock"],
                     help="native = this framework's kernels/DDP/AMP; stock = plain PyTorch-ROCm comparator")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch", "p2p2"],
+                    help="gradient all-reduce back-end: native = this package's RCCL communicator with its own "
+                         "comm stream (auto picks it on GPUs), torch = torch.distributed's process group, "
+                         "p2p2 = the peer-memory two-shot all-reduce kernel")
+    ap.add_argument("--wire-dtype", default="auto", choices=["auto", "fp16", "bf16", "fp32"],
+                    help="gradient dtype on the links (auto = the AMP compute dtype)")
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="stock engine only")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=-1)
     ap.add_argument("--graph", action="store_true",
                     help="record the step into a hipGraph after warm-up and replay it (single GPU, native engine)")
-    ap.add_argument("--native-comm", action="store_true",
-                    help="gradient all-reduce through this package's own RCCL communicator instead of torch.distributed")
+    ap.add_argument("--native-comm", action="store_true", help="same as --comm native")
     ap.add_argument("--autotune", action=argparse.BooleanOptionalAction, default=True,
                     help="backends.benchmark: time the candidate conv tile configurations per layer shape during "
                          "warm-up (the reference sets cudnn.benchmark = True, /root/reference/2.distributed.py:122)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
                          "all-reduce path on a single GPU)")
-    return ap.parse_args()
+    ap.add_argument("--compare-stock", action="store_true",
+                    help="after the native timing, time the stock PyTorch-ROCm engine (channels-last autocast + "
+                         "GradScaler + torch SGD, same model / batch / steps) in the same process and report "
+                         "vs_stock = native / stock")
+    ap.add_argument("--stage-timeout", type=float, default=float(os.environ.get("PDA_BENCH_STAGE_TIMEOUT", "300")),
+                    help="seconds any single blocking stage may take before the run is declared hung")
+    ap.add_argument("--master-port", type=int, default=0, help="supervisor mode: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------
+# supervisor: python bench.py --gpus N with no launcher around it
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(args, argv, comm: str):
+    """Start args.gpus ranks through the package's launcher; returns (rc, json line or None, tail of output)."""
+    port = args.master_port or _free_port()
+    cmd = [sys.executable, "-u", "-m", "pytorch_distributed_amd.launch", "--nproc_per_node", str(args.gpus),
+           "--master_addr", "127.0.0.1", "--master_port", str(port), os.path.abspath(__file__)] + argv
+    if comm:
+        cmd += ["--comm", comm]
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # whole-run bound: every stage of every rank has its own deadline; this one only catches a launcher that
+    # itself stops responding
+    limit = 6 * args.stage_timeout + 120
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, cwd=ROOT,
+                         start_new_session=True)
+    lines = []
+
+    def pump():
+        for line in p.stdout:
+            lines.append(line.rstrip("\n"))
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = p.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, 15)
+            time.sleep(5)
+            os.killpg(p.pid, 9)
+        except OSError:
+            pass
+        rc = 124
+    t.join(timeout=5)
+    result = err = None
+    for l in lines:
+        if l.startswith("{"):
+            try:
+                d = json.loads(l)
+            except ValueError:
+                continue
+            if "metric" in d and "value" in d:
+                result = d
+            elif "error" in d and err is None:
+                err = d
+    for l in lines:
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    return rc, result, err
+
+
+def supervise(args, argv) -> int:
+    # drop the options the supervisor sets itself
+    clean, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("--comm", "--master-port"):
+            skip = True
+            continue
+        if a.startswith("--comm=") or a.startswith("--master-port=") or a == "--native-comm":
+            continue
+        clean.append(a)
+    first = "native" if args.native_comm and args.comm == "auto" else args.comm
+    attempts = [first]
+    if first in ("auto", "native") and os.environ.get("PDA_BENCH_DEVICE", "") != "cpu" and args.engine == "native":
+        attempts.append("torch")
+    last_err = None
+    for i, comm in enumerate(attempts):
+        rc, result, err = _run_ranks(args, clean, comm)
+        if rc == 0 and result is not None:
+            if result.get("n_gpus") != args.gpus:
+                print(json.dumps({"error": f"asked for {args.gpus} ranks, the job reported {result.get('n_gpus')}"}))
+                return 1
+            if i > 0:
+                result.setdefault("config", {})["comm_fallback_from"] = attempts[0]
+                result["config"]["comm_fallback_reason"] = (last_err or {}).get("error", "first attempt failed")
+            print(json.dumps(result), flush=True)
+            return 0
+        last_err = err or {"error": f"ranks exited with code {rc} and no result line"}
+        print(f"[bench] attempt with --comm {comm} failed (rc {rc}): {last_err.get('error')}", file=sys.stderr, flush=True)
+    print(json.dumps(last_err), flush=True)
+    return 1
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+class Deadline:
+    """``with deadline.stage("name"):`` - a daemon thread ends the process with an error line if the block
+    does not finish within the stage timeout (a hung rendezvous / collective never raises by itself)."""
+
+    def __init__(self, seconds: float, rank: int):
+        self.seconds, self.rank = seconds, rank
+        self._until, self._name = None, ""
+        self._lock = threading.Lock()
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                until, name = self._until, self._name
+            if until is not None and time.time() > until:
+                msg = {"error": f"rank {self.rank}: stage '{name}' did not finish within {self.seconds:.0f} s "
+                                "(hung collective or rendezvous)", "stage": name, "rank": self.rank}
+                print(json.dumps(msg), flush=True)
+                os._exit(3)
+
+    def stage(self, name: str, factor: float = 1.0):
+        dl = self
+
+        class _S:
+            def __enter__(self_s):
+                with dl._lock:
+                    dl._until, dl._name = time.time() + dl.seconds * factor, name
+
+            def __exit__(self_s, *exc):
+                with dl._lock:
+                    dl._until = None
+                return False
+        return _S()
+
+
+def worker(args) -> int:
+    import datetime
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(max(args.local_rank, 0))))
     # PDA_BENCH_DEVICE=cpu: control-flow rehearsal of the multi-rank path (gloo, CPU reference ops) for the
     # test-suite; numbers from it are not benchmark results and the JSON says so in "device".
     on_cpu = os.environ.get("PDA_BENCH_DEVICE", "") == "cpu"
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started {world} rank(s) "
+                                       "(WORLD_SIZE); refusing to report a job of a different size"}), flush=True)
+        return 2
     if not on_cpu and not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; bench.py needs an MI355X"}))
+        return 2
+    if not on_cpu and torch.cuda.device_count() <= local_rank:
+        print(json.dumps({"error": f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} "
+                                   "GPU(s) visible"}), flush=True)
         return 2
     if on_cpu:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)      # before anything else touches the device
         dev = torch.device("cuda", local_rank)
+    deadline = Deadline(args.stage_timeout, rank)
     import torch.distributed as dist
+    from pytorch_distributed_amd import comm as pcomm
     ddp = world > 1 or args.force_ddp
+    comm_kind = "native" if (args.native_comm and args.comm == "auto") else args.comm
+    if comm_kind == "auto":
+        comm_kind = "torch" if (on_cpu or args.engine == "stock") else "native"
+    if on_cpu and comm_kind != "torch":
+        comm_kind = "torch"
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if on_cpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        with deadline.stage("rendezvous"):
+            to = datetime.timedelta(seconds=args.stage_timeout)
+            if on_cpu:
+                pcomm.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+            elif comm_kind == "torch":
+                pcomm.init_process_group("nccl", rank=rank, world_size=world, timeout=to, device_id=dev)
+            else:
+                # control plane on gloo (CPU tensors), data plane on this package's own communicator;
+                # torch only creates an RCCL communicator of its own if something hands it a device tensor
+                pcomm.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=to)
 
     from pytorch_distributed_amd import models, ops, amp, backends
     backends.benchmark = bool(args.autotune) and args.warmup > 0   # the tuning runs belong to the warm-up steps
@@ -92,8 +276,53 @@ def main():
     images = torch.randn(B, 3, S, S, device=dev)
     target = torch.randint(0, args.num_classes, (B,), device=dev)
     cdtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[args.precision]
+    comm_obj = None
+    comm_info = {"comm_backend": None, "rccl_nranks": None, "wire_dtype": None, "buckets": None,
+                 "bucket_mb": args.bucket_mb if ddp else None}
 
-    if args.engine == "native":
+    def make_native_comm():
+        """This package's RCCL communicator, created and proven with one bounded collective before the model
+        depends on it.  Every rank votes (over the gloo control plane) on whether it works; a single failing or
+        stalling rank sends the whole job to torch.distributed's process group instead, and the JSON says so."""
+        ok, why, c = 1, "", None
+        with deadline.stage("RCCL communicator creation", factor=1.0):
+            try:
+                c = pcomm.device_communicator(dev)
+                if c is None:
+                    raise RuntimeError("no communicator")
+                if c.nranks() != world:
+                    raise RuntimeError(f"ncclCommCount = {c.nranks()}, expected {world}")
+                probe = torch.full((1 << 16,), float(rank + 1), device=dev)
+                w = c.all_reduce(probe, "sum", async_op=True)
+                done = w.synchronize(min(60.0, args.stage_timeout)) if hasattr(w, "synchronize") else True
+                if not done:
+                    raise TimeoutError("first all-reduce did not complete in time")
+                w.wait()
+                torch.cuda.synchronize()
+                expect = world * (world + 1) / 2
+                if abs(float(probe[0].item()) - expect) > 1e-3 or abs(float(probe[-1].item()) - expect) > 1e-3:
+                    raise RuntimeError(f"first all-reduce returned {float(probe[0].item())}, expected {expect}")
+            except Exception as e:  # noqa: BLE001 - any failure here is a reason to fall back, never to hang
+                ok, why = 0, f"{type(e).__name__}: {e}"[:300]
+        with deadline.stage("communicator vote"):
+            v = torch.tensor([ok], dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if int(v.item()) == 1:
+            return c
+        comm_info["comm_fallback_reason"] = why or "another rank could not use the native communicator"
+        print(f"[bench] rank {rank}: native RCCL communicator unusable ({comm_info['comm_fallback_reason']}); "
+              "falling back to torch.distributed", file=sys.stderr, flush=True)
+        if c is not None:
+            try:
+                c.abort()
+            except Exception:  # noqa: BLE001
+                pass
+            pcomm._STATE["rccl"].clear()
+        return "torch"
+
+    def build_native():
+        nonlocal comm_obj
         model = models.get_model(args.arch, num_classes=args.num_classes).to(dev)
         if args.sync_bn:
             from pytorch_distributed_amd.nn import SyncBatchNorm
@@ -104,9 +333,22 @@ def main():
                                     verbosity=0)
         if ddp:
             from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
-            model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=args.bucket_mb,
-                        force_comm=args.force_ddp,
-                        comm="native" if args.native_comm else None)
+            kind = comm_kind
+            if kind == "native":
+                kind = make_native_comm()
+            with deadline.stage("parameter broadcast"):
+                model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=args.bucket_mb,
+                            force_comm=args.force_ddp, comm=kind, wire_dtype=args.wire_dtype)
+                comm_obj = model._coll
+                comm_info["comm_backend"] = getattr(comm_obj, "backend", type(comm_obj).__name__)
+                if hasattr(comm_obj, "nranks"):
+                    comm_info["rccl_nranks"] = comm_obj.nranks()
+                    if comm_info["rccl_nranks"] != world:
+                        raise RuntimeError(f"RCCL communicator has {comm_info['rccl_nranks']} ranks, expected {world}")
+                comm_info["wire_dtype"] = str(model.wire_dtype).replace("torch.", "") if model.wire_dtype else \
+                    str(model._grad_dtype).replace("torch.", "")
+                if not on_cpu:
+                    torch.cuda.synchronize()
         metrics = ops.new_metrics(dev)
 
         def step():
@@ -116,55 +358,88 @@ def main():
                 scaled.backward()
             opt.step()
             return loss
-    else:
+        return model, step
+
+    def build_stock(channels_last: bool):
         model = models.torch_resnet(args.arch, args.num_classes).to(dev)
         x = images
-        if args.channels_last:
+        if channels_last:
             model = model.to(memory_format=torch.channels_last)
             x = images.contiguous(memory_format=torch.channels_last)
         opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-        scaler = torch.amp.GradScaler("cuda", enabled=(cdtype == torch.float16))
+        scaler = torch.amp.GradScaler("cuda", enabled=(cdtype == torch.float16 and not on_cpu))
         if ddp:
             model = torch.nn.parallel.DistributedDataParallel(model, device_ids=None if on_cpu else [local_rank])
+            comm_info["comm_backend"] = "torch.distributed:" + dist.get_backend()
         crit = torch.nn.CrossEntropyLoss()
 
         def step():
             opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=cdtype, enabled=(cdtype != torch.float32)):
+            with torch.autocast("cpu" if on_cpu else "cuda", dtype=cdtype if not on_cpu else torch.bfloat16,
+                                enabled=(cdtype != torch.float32)):
                 loss = crit(model(x), target)
             scaler.scale(loss).backward()
             scaler.step(opt)
             scaler.update()
             return loss
+        return model, step
 
     def fence():
         if world > 1:
-            dist.barrier()
+            if comm_obj is not None and hasattr(comm_obj, "nranks"):
+                comm_obj.barrier(timeout_s=args.stage_timeout)    # device all-reduce on the data-plane communicator
+            else:
+                dist.barrier()
         if not on_cpu:
             torch.cuda.synchronize()
 
+    def timed(step):
+        with deadline.stage("warm-up", factor=2.0):
+            loss = None
+            for _ in range(args.warmup):
+                loss = step()
+            fence()
+        with deadline.stage("timed loop", factor=2.0):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step()
+            fence()
+            dt = time.perf_counter() - t0
+        with deadline.stage("result reduce"):
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            if world > 1:
+                if dist.get_backend() == "nccl":
+                    tmax = tmax.to(dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item()), float(loss.item())
+
+    model, step = build_native() if args.engine == "native" else build_stock(args.channels_last)
+    if ddp and args.engine == "native":
+        comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
+                                 "params": b["params"]} for b in model.bucket_summary()]
     graphed = False
     if args.graph and args.engine == "native" and not ddp:
         from pytorch_distributed_amd.utils.graph import GraphedStep
-        eager_step = step
-        step = GraphedStep(eager_step, warmup=min(3, max(args.warmup, 1)))
+        step = GraphedStep(step, warmup=min(3, max(args.warmup, 1)))
         graphed = step.captured
 
-    for _ in range(args.warmup):
-        loss = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    final_loss = float(loss.item())
+    dt, final_loss = timed(step)
+    if ddp and args.engine == "native":  # after the arrival-order rebuild
+        comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
+                                 "params": b["params"]} for b in model.bucket_summary()]
+    ips = world * B * args.steps / dt
+    vs_stock = stock_ips = None
+    if args.compare_stock and args.engine == "native" and not on_cpu:
+        del model, step
+        torch.cuda.empty_cache()
+        try:
+            _, sstep = build_stock(True)
+            sdt, _ = timed(sstep)
+            stock_ips = world * B * args.steps / sdt
+            vs_stock = ips / stock_ips
+        except Exception as e:  # noqa: BLE001 - the comparator must not take the headline number down with it
+            stock_ips = f"failed: {type(e).__name__}: {e}"[:200]
     if rank == 0:
-        ips = world * B * args.steps / dt
         out = {
             "metric": ("images/sec (whole node) ResNet-50 fp16 training, synthetic ImageNet 224x224"
                        if (args.arch, args.precision, S) == ("resnet50", "fp16", 224) else
@@ -172,28 +447,50 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_stock": None if vs_stock is None else round(vs_stock, 3),
             "config": {"model": args.arch, "global_batch": world * B, "per_gpu_batch": B, "image_size": S,
                        "seq_len": None, "parallelism": f"dp{world}", "engine": args.engine,
                        "amp_opt_level": args.opt_level if args.precision != "fp32" else "O0",
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
                        "device": "cpu (rehearsal, not a result)" if on_cpu else torch.cuda.get_device_name(dev),
-                       "weights": "random-init", "conv_autotune": backends.benchmark if args.engine == "native" else None, "final_loss": round(final_loss, 4), "hip_graph": graphed,
+                       "weights": "random-init",
+                       "conv_autotune": backends.benchmark if args.engine == "native" else None,
+                       "final_loss": round(final_loss, 4), "hip_graph": graphed,
+                       "comm_backend": comm_info["comm_backend"], "rccl_nranks": comm_info["rccl_nranks"],
+                       "wire_dtype": comm_info["wire_dtype"], "bucket_mb": comm_info["bucket_mb"],
+                       "buckets": comm_info["buckets"],
+                       "comm_fallback_reason": comm_info.get("comm_fallback_reason"),
+                       "stock_images_per_sec": (round(stock_ips, 2) if isinstance(stock_ips, float) else stock_ips),
+                       "stock_comparator": ("same process, same model/batch/steps: torchvision-topology ResNet, "
+                                            "channels_last, torch.autocast + GradScaler + torch.optim.SGD"
+                                            if args.compare_stock else None),
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
         print(json.dumps(out), flush=True)
     if ddp:
-        dist.destroy_process_group()
+        with deadline.stage("teardown"):
+            pcomm.destroy_process_group()
     return 0
 
 
-if __name__ == "__main__":
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return supervise(args, argv)
     try:
-        rc = main()
+        return worker(args)
     except Exception as e:  # noqa: BLE001 - a failed run must still say why, in the one place the driver reads
         import traceback
         traceback.print_exc()
-        if int(os.environ.get("RANK", "0")) == 0:
-            print(json.dumps({"error": f"{type(e).__name__}: {e}"[:500]}), flush=True)
-        rc = 1
-    sys.exit(rc)
+        print(json.dumps({"error": f"rank {os.environ.get('RANK', '0')}: {type(e).__name__}: {e}"[:500]}), flush=True)
+        return 1
+
+
+if __name__ == "__main__":
+    rc = main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # ranks of a failed multi-rank job must not wait in interpreter teardown for peers that are gone
+    os._exit(rc) if rc != 0 and "WORLD_SIZE" in os.environ else sys.exit(rc)

@@ -57,6 +57,7 @@ def _apply_policy(model: torch.nn.Module, opt_level: str, dtype: torch.dtype) ->
         def autocast_forward(*a, **k):
             with torch.autocast(device_type=dev_type, dtype=low if dev_type == "cuda" else torch.bfloat16):
                 return fwd(*a, **k)
+        autocast_forward._pda_autocast_dtype = low
         inner.forward = autocast_forward
 
 
@@ -71,6 +72,8 @@ def _install_master_copies(model: torch.nn.Module, optimizer, dtype: torch.dtype
             half = w.to(dtype)
             cache: WeightCache = m._cache
             cache.pinned_lp = (dtype, half, m.weight._version)
+            from ..ops import conv as _conv
+            _conv._PINNED_SYNCED[half.data_ptr()] = _conv.param_generation()
             optimizer.register_model_copy(m.weight, half)
 
 
@@ -141,6 +144,11 @@ def _attach(optimizer, scaler: LossScaler) -> None:
 
 
 def _grads_of(optimizer):
+    """The gradients the optimizer is going to consume (for a fused optimizer behind a fused-wire
+    DistributedDataParallel these are views of the all-reduced wire buckets, not ``p.grad``)."""
+    if hasattr(optimizer, "attach_scaler"):
+        from ..optim.fused_sgd import effective_grad
+        return [effective_grad(p)[0] for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
     return [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
 
 

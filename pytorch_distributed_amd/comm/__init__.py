@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from .store import TCPStore, FileStore, PrefixStore, Store, StoreTimeout, store_barrier, Heartbeat  # noqa: F401
 
-_STATE = {"store": None, "info": None, "heartbeat": None, "p2p": None, "p2p_tried": False}
+_STATE = {"store": None, "info": None, "heartbeat": None, "p2p": None, "p2p_tried": False, "rccl": {}, "rccl_seq": 0}
 
 
 @dataclass
@@ -156,6 +156,29 @@ def _make_store(init_method: str, rank: int, world_size: int, timeout_s: float):
     raise ValueError(f"unsupported init_method {init_method!r} (use env://, tcp://host:port or file://path)")
 
 
+def _side_store(info: "RankInfo", timeout_s: float):
+    """A native TCPStore next to a process group that was created over somebody else's store: rank 0 binds
+    a free port and tells the others through the group (CPU object broadcast)."""
+    import socket
+    port = [0]
+    if info.rank == 0:
+        s = socket.socket()
+        s.bind(("", 0))
+        port[0] = s.getsockname()[1]
+        s.close()
+    try:
+        if "gloo" in str(dist.get_backend()):
+            dist.broadcast_object_list(port, src=0)
+        else:
+            t = torch.tensor(port, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.broadcast(t, src=0)
+            port[0] = int(t.item())
+        host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        return TCPStore(host, int(port[0]), info.world_size, is_master=(info.rank == 0), timeout=timeout_s)
+    except Exception:  # noqa: BLE001 - the side store is a convenience; everything has a group-based fallback
+        return None
+
+
 def init_process_group(backend: Optional[str] = None, init_method: Optional[str] = None, world_size: int = -1,
                        rank: int = -1, timeout: Optional[datetime.timedelta] = None, store=None,
                        device_id: Optional[torch.device] = None, heartbeat: bool = False) -> RankInfo:
@@ -175,7 +198,11 @@ def init_process_group(backend: Optional[str] = None, init_method: Optional[str]
     if device_id is not None and backend == "nccl":
         kw["device_id"] = device_id
     use_native = os.environ.get("PDA_NATIVE_STORE", "1") == "1" and store is None
-    if use_native:
+    # Under torchrun the launcher's own agent already serves a c10d store on MASTER_PORT (the workers are
+    # told so with TORCHELASTIC_USE_AGENT_STORE): the port is taken and speaks torch's protocol, so the
+    # group rendezvous goes through it and this package's store moves to a port rank 0 picks afterwards.
+    agent_store = (init_method.startswith("env://") and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True")
+    if use_native and not agent_store:
         native = _make_store(init_method, info.rank, info.world_size, timeout.total_seconds())
         _STATE["store"] = native
         store = C10dStoreAdapter(PrefixStore("c10d", native))
@@ -187,6 +214,10 @@ def init_process_group(backend: Optional[str] = None, init_method: Optional[str]
     else:
         dist.init_process_group(backend, init_method=init_method, rank=info.rank, world_size=info.world_size,
                                 timeout=timeout, **kw)
+    if use_native and agent_store and info.world_size > 1:
+        _STATE["store"] = _side_store(info, timeout.total_seconds())
+        if heartbeat and _STATE["store"] is not None:
+            _STATE["heartbeat"] = Heartbeat(PrefixStore("pda", _STATE["store"]), info.rank)
     _STATE["info"] = info
     return info
 
@@ -200,7 +231,48 @@ def rank_info() -> Optional[RankInfo]:
     return _STATE["info"]
 
 
+def device_communicator(device=None, create: bool = True, group=None):
+    """This package's own RCCL communicator for ``device`` over the default group (one per process and
+    device, shared by DistributedDataParallel, the hvd engine, SyncBatchNorm statistics and the metric
+    reduce).  The unique id travels through the native rendezvous store when ``init_process_group`` of
+    this package created one, else through one broadcast over the existing ``torch.distributed`` group.
+    Creation is collective: every rank calls it at the same point.  ``None`` when there is no GPU, no
+    process group, or ``create`` is false and none exists yet."""
+    if not torch.cuda.is_available():
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        return None
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if group is not None and group is not dist.group.WORLD:
+        key = (dev.index, id(group))
+    else:
+        key = (dev.index, None)
+        group = None
+    c = _STATE["rccl"].get(key)
+    if c is not None or not create:
+        return c
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    from .rccl import RcclCommunicator
+    seq = _STATE["rccl_seq"]
+    _STATE["rccl_seq"] = seq + 1
+    st = _STATE["store"] if group is None else None
+    c = RcclCommunicator(dist.get_rank(group), dist.get_world_size(group), dev,
+                         store=PrefixStore(f"rccl{seq}", st) if st is not None else None,
+                         bootstrap_group=group)
+    _STATE["rccl"][key] = c
+    return c
+
+
 def destroy_process_group() -> None:
+    for c in list(_STATE["rccl"].values()):
+        try:
+            c.close()
+        except Exception:  # noqa: BLE001 - teardown goes on
+            pass
+    _STATE["rccl"] = {}
     if _STATE["heartbeat"] is not None:
         _STATE["heartbeat"].stop()
         _STATE["heartbeat"] = None
@@ -241,6 +313,13 @@ def small_all_reduce(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tens
         if (p2p is not None and t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= p2p.max_elems
                 and t.device == p2p.device):
             return p2p.all_reduce(t, op)
+        nat = device_communicator(t.device, create=False)
+        if nat is not None and t.is_contiguous() and t.dtype in (torch.float32, torch.float16, torch.bfloat16,
+                                                                torch.float64, torch.int32, torch.int64):
+            nat.all_reduce(t, "sum")
+            if op == "avg":
+                t /= nat.world_size
+            return t
     dist.all_reduce(t, group=group)
     if op == "avg":
         t /= dist.get_world_size(group)
@@ -261,6 +340,7 @@ def barrier() -> None:
 
 
 __all__ = ["RankInfo", "discover", "slurm_world", "init_process_group", "destroy_process_group", "native_store",
+           "device_communicator",
            "enable_p2p_small_allreduce", "small_all_reduce",
            "rank_info", "get_rank", "get_world_size", "barrier", "TCPStore", "FileStore", "PrefixStore", "Store",
            "StoreTimeout", "store_barrier", "Heartbeat", "C10dStoreAdapter"]

@@ -10,9 +10,10 @@
 // Every block walks one chunk with 4-element vectors (16 B of fp32 / 8 B of
 // fp16) when all of the tensor's pointers allow it.
 //
-//   scale : out = in * scale, sets *noop_flag if any input is inf/nan (grad
-//           unscale + overflow check in one pass; with scale=1 it is the cast /
-//           flatten / unflatten kernel: out pointers may be views of a bucket)
+//   scale : out = in * scale, sets *noop_flag if any input is inf/nan or a value
+//           leaves the range of a narrower output type (grad unscale + overflow
+//           check in one pass; with scale=1 it is the cast / flatten / unflatten
+//           kernel: out pointers may be views of a bucket)
 //   axpby : out = a*x + b*y with the same finite check
 //   l2norm: per-tensor and global sum of squares
 //   sgd   : unscale + overflow-skip + weight decay + momentum (+nesterov) + update
@@ -78,8 +79,9 @@ mt_scale_kernel(const long long* __restrict__ meta, const int* __restrict__ blk,
     ld4<TI>(in, i, end, al, v);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      bad = bad || !isfinite(v[k]);
       v[k] *= sc;
+      // a finite fp32 value beyond the fp16 range becomes inf on the store: flag that as well
+      bad = bad || !isfinite(sizeof(TO) < sizeof(TI) ? ElemTraits<TO>::to_f32(ElemTraits<TO>::from_f32(v[k])) : v[k]);
     }
     st4<TO>(out, i, end, al, v);
   }
@@ -153,7 +155,7 @@ __global__ void sqrt_inplace_kernel(float* x, int n) {
 template <typename TG, typename TM, bool HAS_MODEL>
 __global__ void __launch_bounds__(256)
 mt_sgd_kernel(const long long* __restrict__ meta, const int* __restrict__ blk, const float* __restrict__ hp,
-              const float* __restrict__ dev_scale, const int* __restrict__ noop_flag, int first_run) {
+              const float* __restrict__ dev_scale, const int* __restrict__ noop_flag, int first_run, float gscale) {
   if (noop_flag && *noop_flag) return;  // overflow somewhere: skip the whole step
   constexpr int L = HAS_MODEL ? 4 : 3;
   const int ti = blk[blockIdx.x * 2], ci = blk[blockIdx.x * 2 + 1];
@@ -164,7 +166,9 @@ mt_sgd_kernel(const long long* __restrict__ meta, const int* __restrict__ blk, c
   const long long n = meta[ti * (L + 1) + L];
   const float lr = hp[0], mom = hp[1], damp = hp[2], wd = hp[3];
   const bool nesterov = hp[4] != 0.f;
-  const float inv = dev_scale ? 1.f / *dev_scale : 1.f;
+  // gscale: what is still owed to the gradient besides the loss scale (1/world of a SUM all-reduce
+  // whose result is consumed straight from the wire buffer)
+  const float inv = dev_scale ? gscale / *dev_scale : gscale;
   bool al = al4<TG>(g) && al4<float>(p) && al4<float>(mbuf);
   if (HAS_MODEL) al = al && al4<TM>(pm);
   const long long beg = (long long)ci * MT_CHUNK;
@@ -271,10 +275,10 @@ PDA_EXPORT int pda_sqrt_inplace(float* x, int n, hipStream_t st) {
 
 PDA_EXPORT int pda_mt_sgd(int dt_grad, int dt_model, const long long* meta, const int* blk, int nblocks,
                           const float* hp, const float* dev_scale, const int* noop_flag, int first_run,
-                          hipStream_t st) {
+                          float gscale, hipStream_t st) {
   if (nblocks == 0) return 0;
 #define L_SGD(TG, TM, HM) \
-  hipLaunchKernelGGL((mt_sgd_kernel<TG, TM, HM>), dim3(nblocks), dim3(256), 0, st, meta, blk, hp, dev_scale, noop_flag, first_run)
+  hipLaunchKernelGGL((mt_sgd_kernel<TG, TM, HM>), dim3(nblocks), dim3(256), 0, st, meta, blk, hp, dev_scale, noop_flag, first_run, gscale)
   if (dt_model < 0) {
     if (dt_grad == PDA_F32) L_SGD(float, float, false);
     else if (dt_grad == PDA_F16) L_SGD(f16, float, false);

@@ -28,15 +28,21 @@ def broadcast_parameters(params, root_rank: int = 0) -> None:
         if p is None or not torch.is_tensor(p):
             continue
         t = p.data if isinstance(p, torch.nn.Parameter) else p
-        if t.is_contiguous() or t.dim() != 4:
-            handles.append((None, None, M.broadcast_async_(t if t.is_contiguous() else t.contiguous(), root_rank,
-                                                          name=f"{name}")))
-        else:
+        if t.is_contiguous():
+            handles.append((None, None, M.broadcast_async_(t, root_rank, name=f"{name}")))
+        elif t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
             # dense but permuted storage (channels-last conv weights): broadcast the physical buffer
             flat = torch.as_strided(t, (t.numel(),), (1,))
             handles.append((None, None, M.broadcast_async_(flat, root_rank, name=f"{name}")))
-    for _, _, h in handles:
+        else:
+            # a strided view (transposed / sliced tensor): the collective runs on a dense temporary that is
+            # copied back into the view once it has arrived
+            tmp = t.contiguous()
+            handles.append((t, tmp, M.broadcast_async_(tmp, root_rank, name=f"{name}")))
+    for dst, tmp, h in handles:
         M.synchronize(h)
+        if dst is not None:
+            dst.copy_(tmp)
     from ..ops.conv import bump_param_generation
     bump_param_generation()
 

@@ -65,7 +65,7 @@ _SIGS = {
     "pda_mt_axpby": [c_i, c_i, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_p],
     "pda_mt_l2norm": [c_i, c_p, c_p, c_i, c_p, c_i, c_p],
     "pda_sqrt_inplace": [c_p, c_i, c_p],
-    "pda_mt_sgd": [c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p],
+    "pda_mt_sgd": [c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_f, c_p],
     "pda_scaler_update": [c_p, c_p, c_f, c_f, c_i, c_f, c_f, c_p],
     "pda_nchw_to_nhwc": [c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p],
     "pda_relu_fwd": [c_i, c_p, c_p, c_ll, c_p],

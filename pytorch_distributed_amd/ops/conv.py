@@ -30,9 +30,20 @@ _PARAM_GENERATION = 0  # bumped by our optimizers, which update weights behind a
 _STAT_SLOTS_OFF = os.environ.get("PDA_STAT_SLOTS", "0") != "1"
 
 
-def bump_param_generation() -> None:
+# half-precision model copies an optimizer kernel keeps equal to their fp32 masters (amp O2):
+# data_ptr of the copy -> the parameter generation it is current for
+_PINNED_SYNCED: dict = {}
+
+
+def bump_param_generation(synced_copies=None) -> None:
+    """Parameters changed behind autograd's back (optimizer kernel, multi-tensor broadcast): cached
+    low-precision / transposed weights are stale.  ``synced_copies``: half copies the caller has just
+    written together with the masters - those stay current."""
     global _PARAM_GENERATION
     _PARAM_GENERATION += 1
+    if synced_copies is not None:
+        for t in synced_copies:
+            _PINNED_SYNCED[t.data_ptr()] = _PARAM_GENERATION
 
 
 def param_generation() -> int:
@@ -324,10 +335,15 @@ class WeightCache:
         if w.dtype == dtype:
             return w
         if self.pinned_lp is not None and self.pinned_lp[0] == dtype:
-            if self.pinned_lp[2] != weight._version:  # changed through torch (load_state_dict, init): re-sync
-                self.pinned_lp[1].copy_(w)
-                self.pinned_lp = (dtype, self.pinned_lp[1], weight._version)
-            return self.pinned_lp[1]
+            half = self.pinned_lp[1]
+            # stale when the master changed through torch (load_state_dict, init: version counter) or
+            # through a raw kernel that is not the optimizer owning this copy (parameter broadcast of a
+            # DistributedDataParallel / hvd.broadcast_parameters: generation counter)
+            if self.pinned_lp[2] != weight._version or _PINNED_SYNCED.get(half.data_ptr()) != _PARAM_GENERATION:
+                half.copy_(w)
+                self.pinned_lp = (dtype, half, weight._version)
+                _PINNED_SYNCED[half.data_ptr()] = _PARAM_GENERATION
+            return half
         key = self._key(weight, dtype)
         if self.key_lp != key:
             self.lp = w.to(dtype)

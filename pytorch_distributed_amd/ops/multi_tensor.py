@@ -93,6 +93,8 @@ def scale(tl: TensorLists, scale_value: float = 1.0, dev_scale: Optional[torch.T
         af = _flat(a).float()
         bad = bad or not bool(torch.isfinite(af).all())
         _flat(b).copy_(af * s)
+        if b.dtype != a.dtype and b.element_size() < a.element_size():
+            bad = bad or not bool(torch.isfinite(_flat(b).float()).all())
     if bad and noop_flag is not None:
         noop_flag.fill_(1)
 
@@ -135,12 +137,13 @@ def l2norm(tl: TensorLists, per_tensor: bool = False):
 
 
 def sgd(tl: TensorLists, hp: torch.Tensor, first_run: bool, dev_scale: Optional[torch.Tensor] = None,
-        noop_flag: Optional[torch.Tensor] = None) -> None:
+        noop_flag: Optional[torch.Tensor] = None, grad_scale: float = 1.0) -> None:
     """Fused momentum-SGD over lists (grads, fp32 params, momentum buffers[, model copies]).
 
     ``hp`` = float tensor {lr, momentum, dampening, weight_decay, nesterov} on the
     parameters' device; ``dev_scale`` the loss scale the grads still carry;
-    ``noop_flag`` non-zero skips the whole update (gradient overflow).
+    ``noop_flag`` non-zero skips the whole update (gradient overflow); ``grad_scale`` is an extra
+    factor on the gradient (the 1/world of a SUM all-reduce consumed straight from its wire buffer).
     """
     grads, params, bufs = tl.lists[0], tl.lists[1], tl.lists[2]
     models = tl.lists[3] if len(tl.lists) > 3 else None
@@ -151,12 +154,12 @@ def sgd(tl: TensorLists, hp: torch.Tensor, first_run: bool, dev_scale: Optional[
         l = _lib.lib()
         _lib.check(l.pda_mt_sgd(_lib.dt(grads[0]), _lib.dt(models[0]) if models else -1, meta.data_ptr(),
                                 blk.data_ptr(), nb, hp.data_ptr(), _lib.ptr(dev_scale), _lib.ptr(noop_flag),
-                                int(first_run), _lib.stream()), "pda_mt_sgd")
+                                int(first_run), float(grad_scale), _lib.stream()), "pda_mt_sgd")
         return
     if noop_flag is not None and int(noop_flag) != 0:
         return
     lr, mom, damp, wd, nest = [float(v) for v in hp.tolist()]
-    inv = 1.0 / float(dev_scale) if dev_scale is not None else 1.0
+    inv = (1.0 / float(dev_scale) if dev_scale is not None else 1.0) * float(grad_scale)
     for i, (g, p, m) in enumerate(zip(grads, params, bufs)):
         gf = _flat(g).float() * inv + wd * _flat(p)
         if mom != 0.0:

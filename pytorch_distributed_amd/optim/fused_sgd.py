@@ -27,6 +27,17 @@ from ..ops import multi_tensor as mt
 from ..ops.conv import bump_param_generation
 
 
+def effective_grad(p: torch.Tensor):
+    """``(gradient tensor, factor still owed to it)`` the optimizer consumes for ``p``: normally
+    ``(p.grad, 1.0)``; a DistributedDataParallel wrapper in fused-wire mode hands over a view of the
+    all-reduced low-precision wire bucket instead (``p._pda_wire_grad``), so the reduced gradient is never
+    cast back into ``p.grad``."""
+    w = getattr(p, "_pda_wire_grad", None)
+    if w is not None:
+        return w
+    return p.grad, 1.0
+
+
 def _dense_like(p: torch.Tensor) -> bool:
     return p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
 
@@ -47,6 +58,12 @@ class FusedSGD(Optimizer):
             for p in g["params"]:
                 # let this package's conv ops accumulate weight gradients straight into an existing .grad
                 p._pda_direct_grad = True
+                # a DistributedDataParallel wrapper may keep reduced gradients in its wire buckets for us
+                p._pda_fused_opt = True
+                ddp = getattr(p, "_pda_ddp", None)
+                ddp = ddp() if ddp is not None else None
+                if ddp is not None:
+                    ddp.enable_fused_wire()
 
     # -- mixed precision hooks -------------------------------------------------------------
     def attach_scaler(self, scaler) -> None:
@@ -154,19 +171,23 @@ class FusedSGD(Optimizer):
             first = any("momentum_buffer" not in self.state[p] for p in ps) and group["momentum"] != 0
             # partition by (grad dtype, has model copy): one launch each
             buckets: Dict[tuple, List[torch.Tensor]] = {}
+            eff = {}
             for p in ps:
                 mc = self._model_copies.get(id(p))
-                key = (p.grad.dtype, None if mc is None else mc.dtype, "momentum_buffer" in self.state[p])
+                g, gs = effective_grad(p)
+                eff[id(p)] = g
+                key = (g.dtype, None if mc is None else mc.dtype, "momentum_buffer" in self.state[p], float(gs))
                 buckets.setdefault(key, []).append(p)
             for key, plist in buckets.items():
                 fresh = not key[2] and group["momentum"] != 0
                 for p in plist:
                     if "momentum_buffer" not in self.state[p]:
                         self.state[p]["momentum_buffer"] = torch.zeros_like(p, dtype=torch.float32)
-                ck = (gi, key, tuple(id(p) for p in plist), tuple(p.grad.data_ptr() for p in plist))
+                ck = (gi, key, tuple(id(p) for p in plist), tuple(eff[id(p)].data_ptr() for p in plist))
                 tl = self._lists.get(ck)
                 if tl is None:
-                    lists = [[p.grad for p in plist], list(plist), [self.state[p]["momentum_buffer"] for p in plist]]
+                    lists = [[eff[id(p)] for p in plist], list(plist),
+                             [self.state[p]["momentum_buffer"] for p in plist]]
                     if key[1] is not None:
                         lists.append([self._model_copies[id(p)] for p in plist])
                     tl = mt.TensorLists(lists)
@@ -174,8 +195,8 @@ class FusedSGD(Optimizer):
                         self._lists.clear()
                     self._lists[ck] = tl
                 mt.sgd(tl, self._group_hp(gi, group, plist[0].device), first_run=fresh, dev_scale=dev_scale,
-                       noop_flag=noop)
-        bump_param_generation()
+                       noop_flag=noop, grad_scale=key[3])
+        bump_param_generation(self._model_copies.values())
         if scaler is not None and scaler.enabled:
             scaler.after_step()
         return loss

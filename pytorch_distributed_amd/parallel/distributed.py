@@ -21,9 +21,14 @@ and from ``apex.parallel.DistributedDataParallel(model)``
   the producing kernels) the moment its last gradient has been produced, strictly in
   bucket order on every rank; the end-of-backward callback makes the compute stream
   wait for the outstanding collectives and applies the 1/world average;
-* optional ``wire_dtype=torch.float16/bfloat16`` halves the bytes on the links
-  (fp32 accumulate happens inside RCCL per hop; the bucket is cast with one fused
-  multi-tensor kernel each way) - the Horovod ``Compression.fp16`` idea;
+* ``wire_dtype`` (default ``"auto"``: the 16-bit compute dtype ``amp.initialize`` gave the model under
+  O1-O3, else the gradient dtype) halves the bytes on the links - the Horovod ``Compression.fp16`` idea
+  (/root/reference/5.horovod_distributed.py:123).  A ready bucket is cast into its persistent wire
+  buffer by ONE multi-tensor launch that also applies the pre-division (1/world for fp16 so the sum
+  cannot leave the fp16 range) and flags overflow; a fused optimizer (``optim.FusedSGD``) then reads the
+  all-reduced wire buffer directly, with the remaining 1/world folded into its update kernel, so the
+  reduced gradient is never cast back (``fused_wire``); any other optimizer gets it unpacked into
+  ``param.grad`` by one launch per bucket;
 * after the first backward the plan is rebuilt in gradient-arrival order (rank 0's
   order is broadcast so every rank rebuilds identically);
 * module buffers (BatchNorm running stats) are re-broadcast from rank 0 before each
@@ -36,6 +41,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -54,13 +60,16 @@ def _physical_flat(t: torch.Tensor) -> torch.Tensor:
 
 
 class _Bucket:
-    __slots__ = ("index", "flat", "params", "views", "work", "wire", "launched")
+    __slots__ = ("index", "flat", "params", "views", "work", "wire", "launched", "pack", "unpack", "wire_views")
 
     def __init__(self, index, flat, params):
         self.index, self.flat, self.params = index, flat, params
         self.views: List[torch.Tensor] = []
         self.work = None
-        self.wire = None
+        self.wire = None          # persistent low-precision copy that travels over the links
+        self.pack = None          # cached multi-tensor tables: flat -> wire
+        self.unpack = None        # wire -> flat
+        self.wire_views = None    # per-parameter views of the wire buffer (fused optimizer hand-over)
         self.launched = False
 
 
@@ -68,28 +77,46 @@ class DistributedDataParallel(nn.Module):
     def __init__(self, module: nn.Module, device_ids=None, output_device=None, dim: int = 0,
                  broadcast_buffers: bool = True, process_group=None, bucket_cap_mb: float = 25.0,
                  first_bucket_mb: float = 1.0, find_unused_parameters: bool = False,
-                 gradient_as_bucket_view: bool = True, wire_dtype: Optional[torch.dtype] = None,
+                 gradient_as_bucket_view: bool = True, wire_dtype="auto", fused_wire: Optional[bool] = None,
                  gradient_average: bool = True, gradient_predivide_factor: float = 1.0,
                  delay_allreduce: bool = False, message_size: Optional[int] = None,
                  rebuild_buckets: bool = True, check_shapes: bool = True, use_avg_op: bool = False,
                  comm=None, force_comm: Optional[bool] = None):
-        """``comm``: collective back-end - ``None`` = the ``torch.distributed`` group ``process_group``
-        (RCCL under backend "nccl"), ``"native"`` = this package's own RCCL communicator
-        (``comm.rccl.RcclCommunicator``, bootstrapped over the existing group), or any object with that
-        interface.  ``force_comm`` (default: env ``PDA_DDP_FORCE_COMM=1``) runs the collectives even
-        for a single rank, which is how the communication path is exercised on a one-GPU machine."""
+        """``comm``: collective back-end.  ``None`` (default; env ``PDA_DDP_COMM`` overrides) = this
+        package's own RCCL communicator (``comm.rccl.RcclCommunicator``: own comm stream, overlap with
+        backward) when the parameters live on a GPU, the ``torch.distributed`` group ``process_group``
+        (gloo) when they live on the CPU; ``"native"`` / ``"torch"`` / ``"p2p2"`` force one of the own RCCL
+        communicator, ``torch.distributed`` (ProcessGroupNCCL on GPUs) or the peer-memory two-shot
+        all-reduce (``comm.p2p.P2PCollectives``); any object with that interface is used as is.
+        ``force_comm`` (default: env ``PDA_DDP_FORCE_COMM=1``) runs the collectives even for a single
+        rank, which is how the communication path is exercised on a one-GPU machine."""
         super().__init__()
-        from ..comm.rccl import RcclCommunicator, TorchCollectives
-        if comm is None or comm == "native":
+        from ..comm.rccl import TorchCollectives
+        if comm is None:
+            comm = os.environ.get("PDA_DDP_COMM") or None
+        if comm is None or isinstance(comm, str):
             if not (dist.is_available() and dist.is_initialized()):
                 raise RuntimeError("DistributedDataParallel needs an initialised process group "
                                    "(pytorch_distributed_amd.comm.init_process_group)")
             base = TorchCollectives(process_group)
+            dev = next(p for p in module.parameters() if p.requires_grad).device
+            if comm is None:
+                comm = "native" if dev.type == "cuda" else "torch"
             if comm == "native":
-                dev = next(p for p in module.parameters() if p.requires_grad).device
-                comm = RcclCommunicator(base.rank, base.world_size, dev, bootstrap_group=base.group)
-            else:
+                from ..comm import device_communicator
+                comm = device_communicator(dev, group=process_group)
+                if comm is None:
+                    raise RuntimeError("no RCCL communicator could be created for " + str(dev))
+            elif comm == "p2p2":
+                from ..comm.p2p import P2PCollectives
+                from ..comm import native_store, PrefixStore
+                st = native_store()
+                comm = P2PCollectives(base.rank, base.world_size,
+                                      store=PrefixStore("ddp_p2p", st) if st is not None else None)
+            elif comm == "torch":
                 comm = base
+            else:
+                raise ValueError(f"unknown comm {comm!r} (native, torch or p2p2)")
             self.process_group = base.group
         else:
             self.process_group = process_group
@@ -104,7 +131,6 @@ class DistributedDataParallel(nn.Module):
         self.output_device = output_device
         self.broadcast_buffers = broadcast_buffers
         self.find_unused_parameters = find_unused_parameters
-        self.wire_dtype = wire_dtype
         self.gradient_average = gradient_average
         self.predivide = float(gradient_predivide_factor)
         self.delay_allreduce = delay_allreduce
@@ -116,6 +142,29 @@ class DistributedDataParallel(nn.Module):
             raise RuntimeError("DistributedDataParallel: module has no parameter that requires grad")
         self.device = self._params[0].device
         self._on_device = bool(comm.device_collectives)
+        if isinstance(wire_dtype, str):
+            if wire_dtype != "auto":
+                wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None, "none": None}[wire_dtype]
+            else:
+                # mixed precision on (amp.initialize switched a model of this package to a 16-bit compute
+                # dtype, or wrapped a foreign module's forward in autocast): gradients travel in that dtype
+                low = [getattr(m, "compute_dtype", None) for m in module.modules()]
+                low = [d for d in low if d in (torch.float16, torch.bfloat16)]
+                if not low and getattr(module.forward, "_pda_autocast_dtype", None) is not None:
+                    low = [module.forward._pda_autocast_dtype]
+                wire_dtype = low[0] if low and self._active else None
+        if wire_dtype == self._params[0].dtype:
+            wire_dtype = None
+        self.wire_dtype = wire_dtype
+        # fp16 on the wire: pre-divide by the world size so that the SUM stays in range (apex's
+        # gradient_predivide_factor, chosen automatically unless the caller picked one)
+        self._pre = self.predivide
+        if wire_dtype == torch.float16 and self.predivide == 1.0 and gradient_average:
+            self._pre = float(self.world_size)
+        # fused_wire: None = on as soon as a fused optimizer announces itself (FusedSGD does, whether it
+        # is built before or after this wrapper), False = always unpack into param.grad
+        self._fused_wire_allowed = fused_wire is not False
+        self.fused_wire = bool(fused_wire) and wire_dtype is not None
         # SUM + one scale pass by default; RCCL's AVG op saves that pass but is opt-in (use_avg_op)
         self._use_avg_op = (use_avg_op and self._on_device and gradient_average and self.predivide == 1.0
                             and wire_dtype is None)
@@ -141,6 +190,9 @@ class DistributedDataParallel(nn.Module):
             # convolution ops of this package may write straight into .grad and call this instead
             p._pda_direct_grad = True
             p._pda_grad_ready = self._make_direct_ready(i)
+            p._pda_ddp = weakref.ref(self)
+            if getattr(p, "_pda_fused_opt", False):
+                self.enable_fused_wire()
 
     # ------------------------------------------------------------------ construction helpers
     def _verify_shapes(self) -> None:
@@ -267,15 +319,34 @@ class DistributedDataParallel(nn.Module):
         for b in self._plan.mark_ready(i):
             self._launch(self._buckets[b])
 
+    def enable_fused_wire(self) -> None:
+        """Called by a fused optimizer that consumes ``optim.fused_sgd.effective_grad``: from now on the
+        reduced gradients stay in the wire buckets (``param.grad`` keeps the local gradient)."""
+        if self._fused_wire_allowed and self.wire_dtype is not None:
+            self.fused_wire = True
+
+    def _wire_of(self, bk: _Bucket) -> torch.Tensor:
+        if bk.wire is None:
+            bk.wire = torch.zeros_like(bk.flat, dtype=self.wire_dtype)
+            bk.pack = mt.TensorLists([[bk.flat], [bk.wire]])
+            bk.unpack = mt.TensorLists([[bk.wire], [bk.flat]])
+            esz = self._params[0].element_size()
+            bk.wire_views = []
+            for i in bk.params:
+                p = self._params[i]
+                off = self._plan.offset_of(i) // esz
+                bk.wire_views.append(torch.as_strided(bk.wire, p.shape, p.stride(), off)
+                                     if p.is_contiguous() or _dense(p) else bk.wire[off:off + p.numel()].view_as(p))
+        return bk.wire
+
     def _launch(self, bk: _Bucket) -> None:
         buf = bk.flat
-        if self.predivide != 1.0:
-            buf.mul_(1.0 / self.predivide)
-        if self.wire_dtype is not None and self.wire_dtype != buf.dtype:
-            if bk.wire is None:
-                bk.wire = torch.empty_like(buf, dtype=self.wire_dtype)
-            mt.scale(mt.TensorLists([[buf], [bk.wire]]), 1.0)
-            buf = bk.wire
+        if self.wire_dtype is not None:
+            wire = self._wire_of(bk)
+            mt.scale(bk.pack, 1.0 / self._pre)      # cast + pre-division, one launch for the whole bucket
+            buf = wire
+        elif self._pre != 1.0:
+            buf.mul_(1.0 / self._pre)
         bk.work = self._coll.all_reduce(buf, "avg" if self._use_avg_op else "sum", async_op=True)
         bk.launched = True
 
@@ -292,16 +363,20 @@ class DistributedDataParallel(nn.Module):
                 self._launch(self._buckets[b])
         post = 1.0
         if self.gradient_average and not self._use_avg_op:
-            post = self.predivide / self.world_size
-        elif not self.gradient_average and self.predivide != 1.0:
-            post = self.predivide
+            post = self._pre / self.world_size
+        elif not self.gradient_average and self._pre != 1.0:
+            post = self._pre
         for bk in self._buckets:
             if bk.work is None:
                 continue
             bk.work.wait()
             bk.work = None
             if bk.wire is not None and self.wire_dtype is not None:
-                mt.scale(mt.TensorLists([[bk.wire], [bk.flat]]), post)
+                if self.fused_wire:
+                    for i, v in zip(bk.params, bk.wire_views):
+                        self._params[i]._pda_wire_grad = (v, post)
+                else:
+                    mt.scale(bk.unpack, post)
             elif post != 1.0:
                 bk.flat.mul_(post)
             bk.launched = False
@@ -337,10 +412,24 @@ class DistributedDataParallel(nn.Module):
         """Accumulate gradients locally; the next backward outside the context reduces them."""
         old = self.require_backward_grad_sync
         self.require_backward_grad_sync = False
+        self._drop_wire_handover()
         try:
             yield
         finally:
             self.require_backward_grad_sync = old
+
+    def _drop_wire_handover(self) -> None:
+        for p in self._params:
+            if getattr(p, "_pda_wire_grad", None) is not None:
+                p._pda_wire_grad = None
+
+    def reduced_grad(self, param: torch.Tensor) -> torch.Tensor:
+        """The all-reduced (averaged) gradient of ``param`` as an fp32 tensor, wherever it currently lives
+        (``param.grad``, or the wire bucket in fused-wire mode)."""
+        w = getattr(param, "_pda_wire_grad", None)
+        if w is not None:
+            return w[0].float() * w[1]
+        return param.grad
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """One memset per bucket; keeps ``param.grad`` pointing into the buckets."""
@@ -356,8 +445,9 @@ class DistributedDataParallel(nn.Module):
                 p.grad = None
 
     def bucket_summary(self) -> List[dict]:
-        return [{"bucket": bk.index, "bytes": bk.flat.numel() * bk.flat.element_size(), "params": len(bk.params)}
-                for bk in self._buckets]
+        wsz = torch.empty((), dtype=self.wire_dtype).element_size() if self.wire_dtype is not None else None
+        return [{"bucket": bk.index, "bytes": bk.flat.numel() * bk.flat.element_size(), "params": len(bk.params),
+                 "wire_bytes": bk.flat.numel() * (wsz or bk.flat.element_size())} for bk in self._buckets]
 
     def train(self, mode: bool = True):
         super().train(mode)

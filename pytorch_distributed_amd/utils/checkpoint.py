@@ -57,10 +57,16 @@ def build_state(model, epoch: int, arch: str, best_acc1: float, optimizer=None, 
     return state
 
 
-def load_checkpoint(path: str, model=None, optimizer=None, map_location="cpu", strict: bool = True) -> dict:
+def load_checkpoint(path: str, model=None, optimizer=None, map_location="cpu", strict: bool = True,
+                    trusted: bool = False) -> dict:
     """Load a checkpoint written by ``save_checkpoint`` (or by the reference scripts) and
-    restore model / optimizer / amp state.  Returns the payload (``epoch`` = next epoch)."""
-    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    restore model / optimizer / amp state.  Returns the payload (``epoch`` = next epoch).
+
+    The file is read with the tensors-and-plain-containers loader (``weights_only=True``): the payload
+    is tensors, numbers, strings, dicts and lists, so nothing in a checkpoint needs code execution and a
+    file that carries any other pickled object is refused.  ``trusted=True`` (a file this job wrote
+    itself, carrying custom objects in ``extra``) opts into the full unpickler."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=not trusted)
     if model is not None:
         sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
         wrapped = hasattr(model, "module")

@@ -702,7 +702,7 @@ def test_mnist_net_gpu_matches_cpu():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-@pytest.mark.parametrize("backend", ["torch", "native"])
+@pytest.mark.parametrize("backend", ["torch", "native", "native-inorder"])
 def test_ddp_single_rank_rccl_matches_plain_model(tmp_path, backend):
     """The bucketed-all-reduce engine on the GPU (RCCL, one rank, collectives forced on): gradients
     accumulated straight into bucket views by the conv / BatchNorm kernels, all-reduced per bucket
@@ -722,13 +722,19 @@ def test_ddp_single_rank_rccl_matches_plain_model(tmp_path, backend):
         wrapped = models.get_model("resnet18", num_classes=10).to(DEV)
         wrapped.load_state_dict(plain.state_dict())
         opt = FusedSGD(wrapped.parameters(), lr=0.05, momentum=0.9)
-        ddp = DDP(wrapped, device_ids=[0], bucket_cap_mb=4.0, force_comm=True,
-                  comm="native" if backend == "native" else None)
+        comm = "torch"
+        if backend.startswith("native"):
+            # "native" = the default: collectives on the communicator's own comm stream, issued from the
+            # autograd hooks while backward is still running (overlap), event hand-off back to the compute stream
+            from pytorch_distributed_amd.comm.rccl import RcclCommunicator
+            comm = RcclCommunicator(0, 1, torch.device(DEV, 0), overlap=(backend == "native"))
+            assert comm.overlap == (backend == "native") and comm.nranks() == 1
+        ddp = DDP(wrapped, device_ids=[0], bucket_cap_mb=4.0, force_comm=True, comm=comm)
         assert ddp._active and len(ddp._buckets) > 1
         x = torch.randn(8, 3, 32, 32, device=DEV)
         t = torch.randint(0, 10, (8,), device=DEV)
         F.cross_entropy(plain(x).float(), t).backward()
-        for it in range(2):                      # second pass: direct accumulation into the bucket views
+        for it in range(4):                      # later passes: direct accumulation into the bucket views
             ddp.zero_grad()
             F.cross_entropy(ddp(x).float(), t).backward()
             torch.cuda.synchronize()
