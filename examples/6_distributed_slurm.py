@@ -7,7 +7,13 @@ One SLURM task per node spawns one worker per local GPU; rendezvous is ``file://
 on the shared filesystem.  Unlike upstream, the world size is tasks x GPUs-per-task (upstream uses
 the task count alone, which only works with one GPU per node) and only global rank 0 writes
 checkpoints and the epoch CSV.  Off-cluster the SLURM variables default to a single node, so the
-script also runs stand-alone."""
+script also runs stand-alone.
+
+    ... 6_distributed_slurm.py --dataset imagenet --data /path/to/imagenet -a resnet50 -b 3200
+
+reads ``/path/to/imagenet/{train,val}/<class>/*.JPEG`` through this package's ImageFolder with
+RandomResizedCrop(224) + flip / Resize(256) + CenterCrop(224) (upstream lines 126-159); the loader ships
+uint8 batches and the model's stem kernel normalises them on the GPU."""
 import os
 
 import _common  # noqa: F401

@@ -20,7 +20,7 @@ import torch
 from . import amp as _amp
 from . import models, ops, utils
 from .data import (DistributedSampler, make_loader, cifar10, synthetic_imagenet, SyntheticImages, DevicePrefetcher,
-                   CIFAR10_MEAN, CIFAR10_STD)
+                   CIFAR10_MEAN, CIFAR10_STD, IMAGENET_MEAN, IMAGENET_STD, imagenet, imagenet_available)
 
 
 def build_parser(description: str = "PyTorch ImageNet Training", arch: str = "resnet18", epochs: int = 2,
@@ -65,7 +65,14 @@ def build_parser(description: str = "PyTorch ImageNet Training", arch: str = "re
 
 
 def make_datasets(args):
+    """``--dataset imagenet --data DIR``: ``DIR/train`` and ``DIR/val`` image folders with the reference's
+    augmentation (/root/reference/6.distributed_slurm_main.py:126-159) when they exist (or ``--no-synthetic``
+    insists on them); the batches are raw uint8 and ``fit`` arranges for the normalisation to happen on the
+    device.  Otherwise synthetic data of the dataset's shape."""
     if args.dataset == "imagenet":
+        if args.synthetic is False or (args.synthetic is None and imagenet_available(args.data)):
+            args.input_uint8 = (IMAGENET_MEAN, IMAGENET_STD)
+            return imagenet(args.data, True), imagenet(args.data, False)
         n = args.steps_per_epoch * args.batch_size if args.steps_per_epoch else None
         return synthetic_imagenet(True, n), synthetic_imagenet(False, min(n or 50000, 50000))
     return cifar10(args.data, True, args.synthetic), cifar10(args.data, False, args.synthetic)
@@ -258,6 +265,17 @@ def fit(args, model, optimizer, device, train_set, val_set, per_rank_batch: int,
     pin = device.type == "cuda"
     train_loader = make_loader(train_set, per_rank_batch, train_sampler, args.workers, pin, shuffle=True)
     val_loader = make_loader(val_set, per_rank_batch, val_sampler, args.workers, pin)
+    # raw uint8 batches (image folders): normalise on the device - inside the stem kernel when the model
+    # has one that does it, else on the prefetcher's side stream
+    norm = getattr(args, "input_uint8", None)
+    prefetch_norm = None
+    if norm is not None:
+        inner = model.module if hasattr(model, "module") else model
+        if hasattr(inner, "set_input_normalization"):
+            inner.set_input_normalization(norm[0], norm[1], 1.0 / 255.0)
+        else:
+            prefetch_norm = norm
+            val_loader = DevicePrefetcher(val_loader, device, normalize=norm, channels_scale=255.0)
     chief = (_rank() == 0) if is_chief is None else is_chief
     best_acc1 = 0.0
     if args.resume:
@@ -275,7 +293,8 @@ def fit(args, model, optimizer, device, train_set, val_set, per_rank_batch: int,
             train_sampler.set_epoch(epoch)
             val_sampler.set_epoch(epoch)
         utils.adjust_learning_rate(optimizer, epoch, args.lr)
-        tl = DevicePrefetcher(train_loader, device) if pin else train_loader
+        tl = DevicePrefetcher(train_loader, device, normalize=prefetch_norm, channels_scale=255.0) \
+            if (pin or prefetch_norm is not None) else train_loader
         train(tl, model, criterion, optimizer, epoch, device, args, zero_grad, jsonl=jsonl)
         acc1 = validate(val_loader, model, criterion, device, args, val_sampler)
         is_best = acc1 > best_acc1

@@ -197,6 +197,23 @@ class ResNet(tnn.Module):
             layers.append(block(self.inplanes, planes, base_width=self.base_width, groups=self.groups))
         return tnn.Sequential(*layers)
 
+    def set_input_normalization(self, mean, std, scale: float = 1.0) -> "ResNet":
+        """Normalise inside the stem kernel: input * ``scale`` (1/255 for raw ``uint8`` batches), minus
+        ``mean``, divided by ``std`` per channel - the loader then ships bytes, not floats."""
+        dev = self.conv1.weight.device
+        self._in_mean = torch.tensor(mean, dtype=torch.float32, device=dev)
+        self._in_inv_std = 1.0 / torch.tensor(std, dtype=torch.float32, device=dev)
+        self.input_scale = float(scale)
+        return self
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        for n in ("_in_mean", "_in_inv_std"):       # plain attributes when set after construction
+            t = self.__dict__.get(n)
+            if torch.is_tensor(t):
+                self.__dict__[n] = fn(t)
+        return r
+
     def set_compute_dtype(self, dtype: torch.dtype) -> "ResNet":
         """Activation / MFMA input dtype (fp32, fp16 or bf16); parameters stay fp32 masters."""
         assert dtype in (torch.float32, torch.float16, torch.bfloat16)
