@@ -231,10 +231,13 @@ class RcclCommunicator:
     def _cur(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _done(self, ticket: int, what: str, async_op: bool, keep):
+    def _ov(self, stream_ordered: bool) -> int:
+        return 0 if stream_ordered else int(self.overlap)
+
+    def _done(self, ticket: int, what: str, async_op: bool, keep, stream_ordered: bool = False):
         if ticket is None or ticket < 0:
             raise self._err(what)
-        if not self.overlap:
+        if not self.overlap or stream_ordered:
             return _DoneWork() if async_op else None      # already in the caller's stream order
         w = _RcclWork(self, ticket, keep)
         if async_op:
@@ -258,11 +261,13 @@ class RcclCommunicator:
         return rc == 0
 
     # -- collectives ------------------------------------------------------------------------
-    def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
+    def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False, stream_ordered: bool = False):
+        """``stream_ordered=True``: run as the next operation of the caller's current stream whatever the
+        communicator's overlap setting (callers that already sit on a side stream of their own)."""
         t = self._prep(t)
         k = self._l.pda_rccl_all_reduce(self._h, t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], _OPS[op],
-                                        self._cur(), int(self.overlap))
-        return self._done(k, "all_reduce", async_op, t)
+                                        self._cur(), self._ov(stream_ordered))
+        return self._done(k, "all_reduce", async_op, t, stream_ordered)
 
     def all_reduce_coalesced(self, tensors, op: str = "sum", async_op: bool = False):
         """Several same-dtype all-reduces as one RCCL group launch (one work object)."""
@@ -277,18 +282,18 @@ class RcclCommunicator:
                                               int(self.overlap))
         return self._done(k, "all_reduce_coalesced", async_op, tuple(ts))
 
-    def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
+    def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False, stream_ordered: bool = False):
         t = self._prep(t)
         k = self._l.pda_rccl_broadcast(self._h, t.data_ptr(), t.numel(), _DT[t.dtype], int(src), self._cur(),
-                                       int(self.overlap))
-        return self._done(k, "broadcast", async_op, t)
+                                       self._ov(stream_ordered))
+        return self._done(k, "broadcast", async_op, t, stream_ordered)
 
-    def all_gather(self, out: torch.Tensor, t: torch.Tensor, async_op: bool = False):
+    def all_gather(self, out: torch.Tensor, t: torch.Tensor, async_op: bool = False, stream_ordered: bool = False):
         t, out = self._prep(t), self._prep(out)
         assert out.numel() == t.numel() * self.world_size and out.dtype == t.dtype
         k = self._l.pda_rccl_all_gather(self._h, t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], self._cur(),
-                                        int(self.overlap))
-        return self._done(k, "all_gather", async_op, (t, out))
+                                        self._ov(stream_ordered))
+        return self._done(k, "all_gather", async_op, (t, out), stream_ordered)
 
     def reduce_scatter(self, out: torch.Tensor, t: torch.Tensor, op: str = "sum", async_op: bool = False):
         t, out = self._prep(t), self._prep(out)

@@ -15,8 +15,10 @@
 //   up to the fusion threshold (64 MiB default): CPU tensors are packed into the
 //   fusion buffer, reduced with one shared-memory all-reduce and unpacked with the
 //   post-scale applied (average = sum * 1/size, exactly once).  Device tensors are
-//   handed, group by group, to an executor callback (python: one flatten kernel +
-//   one RCCL all-reduce on a side stream + one unflatten kernel).
+//   handed, group by group, to an executor callback (python: one pack kernel that
+//   also casts to the wire dtype + one RCCL all-reduce on a side stream + one unpack
+//   kernel that casts back and scales).
+// * All-gathers (equal counts on every rank) are negotiated the same way and run one by one.
 // * A shutdown request travels with the same exchange, so all threads leave together.
 #include <stdint.h>
 #include <string.h>
@@ -43,7 +45,7 @@ int pda_shm_wait(void* h, long long ticket);
 
 namespace {
 
-enum Kind : int { K_ALLREDUCE = 0, K_BROADCAST = 1 };
+enum Kind : int { K_ALLREDUCE = 0, K_BROADCAST = 1, K_ALLGATHER = 2 };
 enum HOp : int { H_SUM = 0, H_PROD = 1, H_MIN = 2, H_MAX = 3, H_AVG = 4 };
 
 size_t dsize(int dt) {
@@ -60,6 +62,7 @@ struct Request {
   std::string name;
   int kind, dtype, op, root, device;
   void* ptr;
+  void* ptr_out = nullptr;  // all-gather: world * count elements
   long long count;
   double prescale, postscale;
   bool announced = false;
@@ -82,13 +85,13 @@ class Engine {
   ~Engine() { shutdown(); }
 
   long long enqueue(const char* name, int kind, void* ptr, long long count, int dtype, int op, int root, int device,
-                    double prescale, double postscale) {
+                    double prescale, double postscale, void* ptr_out = nullptr) {
     std::lock_guard<std::mutex> g(mu_);
     Request r;
     r.handle = ++next_handle_;
     r.name = name;
     r.kind = kind; r.dtype = dtype; r.op = op; r.root = root; r.device = device;
-    r.ptr = ptr; r.count = count; r.prescale = prescale; r.postscale = postscale;
+    r.ptr = ptr; r.ptr_out = ptr_out; r.count = count; r.prescale = prescale; r.postscale = postscale;
     for (auto& q : queue_)
       if (q.name == r.name) {
         status_[r.handle].state = -1;
@@ -243,6 +246,17 @@ class Engine {
     size_t i = 0;
     while (i < ready.size()) {
       Request& r = ready[i];
+      if (r.kind == K_ALLGATHER) {
+        if (r.device == 0) {
+          int rc = pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, r.ptr, r.ptr_out, r.count * (long long)dsize(r.dtype)));
+          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-gather failed");
+        } else {
+          std::vector<Request> g1{r};
+          run_device_group(g1);
+        }
+        ++i;
+        continue;
+      }
       if (r.kind == K_BROADCAST) {
         if (r.device == 0) {
           int rc = pda_shm_wait(shm_, pda_shm_broadcast_async(shm_, r.ptr, r.count * (long long)dsize(r.dtype), r.root));
@@ -400,6 +414,10 @@ PDA_EXPORT void pda_hvd_destroy(void* h) { delete static_cast<Engine*>(h); }
 PDA_EXPORT long long pda_hvd_enqueue(void* h, const char* name, int kind, void* ptr, long long count, int dtype, int op,
                                      int root, int device, double prescale, double postscale) {
   return static_cast<Engine*>(h)->enqueue(name, kind, ptr, count, dtype, op, root, device, prescale, postscale);
+}
+PDA_EXPORT long long pda_hvd_enqueue2(void* h, const char* name, int kind, void* ptr, void* ptr_out, long long count,
+                                      int dtype, int op, int root, int device, double prescale, double postscale) {
+  return static_cast<Engine*>(h)->enqueue(name, kind, ptr, count, dtype, op, root, device, prescale, postscale, ptr_out);
 }
 PDA_EXPORT int pda_hvd_poll(void* h, long long handle) { return static_cast<Engine*>(h)->poll(handle); }
 PDA_EXPORT int pda_hvd_wait(void* h, long long handle, char* err, int cap) {

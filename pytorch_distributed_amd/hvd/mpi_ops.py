@@ -15,8 +15,11 @@ API surface used by the reference (/root/reference/5.horovod_distributed.py:70-7
 Engines: with one process ``size() == 1`` and everything is a no-op copy; on one host the native
 engine (``csrc/runtime/hvd_core.cc``: background thread, name negotiation over shared memory,
 tensor fusion) runs CPU tensors through the shared-memory backend and device tensors through an
-executor that issues one fused RCCL all-reduce per group; across hosts a synchronous
-``torch.distributed`` path is used.
+executor that spends three launches on a fused group whatever its size: ONE multi-tensor pack into the
+persistent fusion buffer that also casts to the wire dtype (``Compression.fp16``) and applies the
+pre-scale, ONE all-reduce on this package's own RCCL communicator (or the peer-memory kernels with
+``PDA_HVD_DEVICE_COMM=p2p``), ONE multi-tensor unpack that casts back and applies average / post-scale;
+across hosts a synchronous ``torch.distributed`` path is used.
 """
 from __future__ import annotations
 
@@ -47,6 +50,9 @@ _runtime.register({
                                             ctypes.c_double, ctypes.c_double]),
     "pda_hvd_poll": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong]),
     "pda_hvd_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_int]),
+    "pda_hvd_enqueue2": (ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     "pda_hvd_cycles": (ctypes.c_longlong, [ctypes.c_void_p]),
     "pda_hvd_fused_groups": (ctypes.c_longlong, [ctypes.c_void_p]),
 })
@@ -95,13 +101,17 @@ class Compression:
 
 
 class _Pending:
-    __slots__ = ("eh", "out", "wire", "ctx", "compression", "post", "event", "name", "done")
+    __slots__ = ("eh", "out", "wire", "ctx", "compression", "post", "pre", "event", "name", "done", "fused_wire",
+                 "src")
 
     def __init__(self):
         self.eh = None
         self.done = False
         self.event = None
         self.post = 1.0
+        self.pre = 1.0
+        self.fused_wire = None   # device path: wire dtype the executor's pack kernel casts to (None = tensor's own)
+        self.src = None          # all-gather: the local contribution
 
 
 class _State:
@@ -122,6 +132,9 @@ class _State:
         self.torch_group_ready = False
         self.multi_host = False
         self.dev_coll = None   # device collectives override (PDA_HVD_DEVICE_COMM=p2p)
+        self.fusion_bufs = {}  # (device, dtype) -> persistent device fusion buffer
+        self.group_tables = {}  # pack / unpack tables of recurring fused groups
+        self.launch_stats = {"device_groups": 0, "device_launches": 0, "max_launches_per_group": 0}
 
 
 _S = _State()
@@ -163,6 +176,16 @@ def init(comm=None, process_sets=None) -> None:
         from ..comm.p2p import P2PCollectives
         dev = torch.device("cuda", int(os.environ.get("PDA_HVD_P2P_DEVICE", str(info.local_rank))))
         _S.dev_coll = P2PCollectives(info.rank, info.world_size, store=PrefixStore("hvdp2p", base), device=dev)
+    elif (torch.cuda.is_available() and os.environ.get("PDA_HVD_DEVICE_COMM", "rccl") == "rccl"
+          and os.environ.get("PDA_HVD_NO_CUDA", "0") != "1" and torch.cuda.device_count() >= info.local_size):
+        # this package's own RCCL communicator on the GPU the rank is going to use (set_device(hvd.local_rank()),
+        # /root/reference/5.horovod_distributed.py:93-94); creation is collective, so it happens here where every
+        # rank is known to be
+        from ..comm import device_communicator
+        try:
+            device_communicator(torch.device("cuda", info.local_rank))
+        except Exception as e:  # noqa: BLE001 - torch.distributed's group remains as the device path
+            print(f"[hvd] rank {info.rank}: own RCCL communicator unavailable ({e}); using torch.distributed")
     _S.exec_cb = _EXEC_T(_device_executor)
     fusion = int(float(os.environ.get("HOROVOD_FUSION_THRESHOLD", str(64 << 20))))
     cycle = float(os.environ.get("HOROVOD_CYCLE_TIME", "1.0"))
@@ -262,9 +285,12 @@ def mpi_threads_supported() -> bool:
 
 
 def engine_stats() -> dict:
+    """Engine counters: negotiation cycles, fused groups, and for device groups the number of device
+    launches (pack + collective + unpack) spent on them."""
     if _S.engine is None:
-        return {"cycles": 0, "fused_groups": 0}
-    return {"cycles": int(_S.lib.pda_hvd_cycles(_S.engine)), "fused_groups": int(_S.lib.pda_hvd_fused_groups(_S.engine))}
+        return dict({"cycles": 0, "fused_groups": 0}, **_S.launch_stats)
+    return dict({"cycles": int(_S.lib.pda_hvd_cycles(_S.engine)),
+                 "fused_groups": int(_S.lib.pda_hvd_fused_groups(_S.engine))}, **_S.launch_stats)
 
 
 # ------------------------------------------------------------------------------- helpers
@@ -295,54 +321,99 @@ def _new_handle(p: _Pending) -> int:
     return h
 
 
+def _device_coll(dev):
+    """Collectives for device tensors: the peer-memory backend when asked for, else this package's own RCCL
+    communicator (shared with DistributedDataParallel), else ``torch.distributed``."""
+    if _S.dev_coll is not None:
+        return _S.dev_coll
+    if os.environ.get("PDA_HVD_DEVICE_COMM", "") != "torch":
+        from ..comm import device_communicator
+        try:
+            c = device_communicator(dev, create=False)
+        except Exception:  # noqa: BLE001
+            c = None
+        if c is not None:
+            return c
+    from ..comm.rccl import TorchCollectives
+    return TorchCollectives()
+
+
+def _fusion_buffer(dev, dtype, numel: int) -> torch.Tensor:
+    key = (str(dev), dtype)
+    buf = _S.fusion_bufs.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(max(numel, 1 << 20), device=dev, dtype=dtype)
+        _S.fusion_bufs[key] = buf
+        _S.group_tables.clear()
+    return buf
+
+
 def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
     """Called from the engine thread with one fused group of device tensors."""
     try:
-        import torch.distributed as dist
         ps = [_S.by_engine[int(handles_ptr[i])] for i in range(n)]
-        dev = ps[0].wire.device
+        dev = ps[0].out.device
         if _S.side_stream is None:
-            _S.side_stream = torch.cuda.Stream(dev)
+            _S.side_stream = torch.cuda.Stream(dev)     # default priority: it waits for and is waited on by compute
+        launches = 0
         with torch.cuda.device(dev), torch.cuda.stream(_S.side_stream):
             for p in ps:
                 if p.event is not None:
                     _S.side_stream.wait_event(p.event)
-            coll = _S.dev_coll
+            coll = _device_coll(dev)
+            kw = {"stream_ordered": True} if getattr(coll, "backend", "") == "rccl-native" else {}
             if kind == 1:
                 for p in ps:
-                    if coll is not None:
-                        coll.broadcast(p.wire, root)
-                    else:
-                        dist.broadcast(p.wire, src=root)
+                    coll.broadcast(p.out, root, **kw)
+                    launches += 1
+            elif kind == 2:
+                for p in ps:
+                    coll.all_gather(p.out, p.src, **kw)
+                    launches += 1
             else:
-                red = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.PRODUCT, 2: dist.ReduceOp.MIN, 3: dist.ReduceOp.MAX,
-                       4: dist.ReduceOp.SUM}[op_code]
                 rname = {0: "sum", 1: "prod", 2: "min", 3: "max", 4: "sum"}[op_code]
-
-                def all_reduce(t):
-                    if coll is not None:
-                        coll.all_reduce(t, rname)
-                    else:
-                        dist.all_reduce(t, op=red)
-                scale = (1.0 / _S.info.world_size) if op_code == 4 else 1.0
-                if n == 1:
-                    all_reduce(ps[0].wire)
-                    if scale != 1.0:
-                        ps[0].wire.mul_(scale)
+                post = ps[0].post * ((1.0 / _S.info.world_size) if op_code == 4 else 1.0)
+                pre = ps[0].pre
+                wire_dt = ps[0].fused_wire or ps[0].out.dtype
+                if n == 1 and wire_dt == ps[0].out.dtype and ps[0].out.is_contiguous():
+                    t = ps[0].out                       # lone uncompressed tensor: reduce in place
+                    if pre != 1.0:
+                        t.mul_(pre)
+                        launches += 1
+                    coll.all_reduce(t, rname, **kw)
+                    launches += 1
+                    if post != 1.0:
+                        t.mul_(post)
+                        launches += 1
                 else:
-                    wires = [p.wire.view(-1) for p in ps]
-                    flat = mt.flatten(wires)
-                    all_reduce(flat)
-                    views, off = [], 0
-                    for w in wires:
-                        views.append(flat[off:off + w.numel()])
-                        off += w.numel()
-                    mt.scale(mt.TensorLists([views, wires]), scale)
+                    outs = [torch.as_strided(p.out, (p.out.numel(),), (1,)) for p in ps]
+                    total = sum(o.numel() for o in outs)
+                    flat = _fusion_buffer(dev, wire_dt, total)
+                    gkey = (flat.data_ptr(), tuple(o.data_ptr() for o in outs), tuple(o.numel() for o in outs))
+                    tabs = _S.group_tables.get(gkey)
+                    if tabs is None:
+                        views, off = [], 0
+                        for o in outs:
+                            views.append(flat[off:off + o.numel()])
+                            off += o.numel()
+                        tabs = (mt.TensorLists([outs, views]), mt.TensorLists([views, outs]))
+                        if len(_S.group_tables) > 256:
+                            _S.group_tables.clear()
+                        _S.group_tables[gkey] = tabs
+                    mt.scale(tabs[0], pre)              # pack + cast to the wire dtype + pre-scale: one launch
+                    coll.all_reduce(flat[:total], rname, **kw)
+                    mt.scale(tabs[1], post)             # unpack + cast back + average / post-scale: one launch
+                    launches += 3
             for p in ps:
                 p.event = torch.cuda.Event()
                 p.event.record(_S.side_stream)
+        if kind == 0:
+            st = _S.launch_stats
+            st["device_groups"] += 1
+            st["device_launches"] += launches
+            st["max_launches_per_group"] = max(st["max_launches_per_group"], launches)
         return 0
-    except Exception as e:  # noqa: BLE001 - must not propagate into the C++ thread
+    except Exception:  # noqa: BLE001 - must not propagate into the C++ thread
         import traceback
         traceback.print_exc()
         return -1
@@ -365,6 +436,24 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
         from .adasum import adasum_allreduce_
         adasum_allreduce_(out)
         p.done = True
+        return _new_handle(p)
+    dense = out.is_contiguous() or (out.dim() == 4 and out.is_contiguous(memory_format=torch.channels_last))
+    if out.is_cuda and _S.engine is not None and dense and out.dtype in _DT:
+        # device tensors keep their dtype here: the executor's pack kernel casts to the wire dtype while it
+        # fills the fusion buffer and its unpack kernel casts back (no per-tensor cast kernels)
+        wire_dt = getattr(compression, "wire", None) if kind == 0 else None
+        if wire_dt is not None and not (out.dtype.is_floating_point and out.dtype != wire_dt):
+            wire_dt = None
+        p.wire, p.ctx, p.fused_wire = out, None, wire_dt
+        p.pre, p.post = float(prescale), float(postscale)
+        p.event = torch.cuda.Event()
+        p.event.record(torch.cuda.current_stream(out.device))
+        eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, out.data_ptr(), out.numel(),
+                                    _DT[wire_dt or out.dtype], _OP_CODE.get(op, 0), root, 1, float(prescale),
+                                    float(postscale))
+        p.eh = int(eh)
+        with _S.lock:
+            _S.by_engine[p.eh] = p
         return _new_handle(p)
     wire, ctx = compression.compress(out)
     if not wire.is_contiguous():
@@ -401,6 +490,8 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
 
 
 def _finish(p: _Pending) -> None:
+    if p.wire is p.out:          # device path: the executor's unpack kernel has already written ``out``
+        return
     if p.post != 1.0:
         p.wire.mul_(p.post)
     res = p.compression.decompress(p.wire, p.ctx)
@@ -484,21 +575,43 @@ def broadcast_(tensor, root_rank, name=None, process_set=None) -> torch.Tensor:
     return synchronize(broadcast_async_(tensor, root_rank, name))
 
 
-def allgather(tensor, name=None, process_set=None) -> torch.Tensor:
-    """Concatenate every rank's tensor along dim 0 (equal shapes across ranks)."""
+def allgather_async(tensor, name=None, process_set=None) -> int:
+    """Every rank's tensor concatenated along dim 0 (equal shapes across ranks): a real all-gather - each
+    rank's bytes travel once - negotiated by name like every other request."""
     _need_init()
     world = _S.info.world_size
-    if world == 1:
-        return tensor.clone()
     t = tensor.contiguous()
     if t.dim() == 0:
         t = t.reshape(1)
-    # every rank fills its own slice of a zero buffer and the slices are summed: this rides on the
-    # name-negotiated all-reduce path, so it is safe next to in-flight asynchronous requests
-    out = torch.zeros((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    out[_S.info.rank].copy_(t)
-    allreduce_(out, name=None if name is None else f"allgather.{name}", op=Sum)
-    return out.reshape((world * t.shape[0],) + tuple(t.shape[1:]))
+    p = _Pending()
+    p.name = _auto_name("allgather", name)
+    p.compression = Compression.none
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    p.out, p.wire, p.src = out, out, t
+    if world == 1:
+        out.copy_(t)
+        p.done = True
+        return _new_handle(p)
+    if t.dtype not in _DT:
+        raise TypeError(f"hvd: unsupported tensor dtype {t.dtype}")
+    if _S.engine is None:  # multi-host fallback: synchronous torch.distributed
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(out, t)
+        p.done = True
+        return _new_handle(p)
+    if t.is_cuda:
+        p.event = torch.cuda.Event()
+        p.event.record(torch.cuda.current_stream(t.device))
+    eh = _S.lib.pda_hvd_enqueue2(_S.engine, p.name.encode(), 2, t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], 0,
+                                 0, 1 if t.is_cuda else 0, 1.0, 1.0)
+    p.eh = int(eh)
+    with _S.lock:
+        _S.by_engine[p.eh] = p
+    return _new_handle(p)
+
+
+def allgather(tensor, name=None, process_set=None) -> torch.Tensor:
+    return synchronize(allgather_async(tensor, name))
 
 
 def barrier(process_set=None) -> None:

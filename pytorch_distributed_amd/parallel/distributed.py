@@ -111,7 +111,7 @@ class DistributedDataParallel(nn.Module):
                 from ..comm.p2p import P2PCollectives
                 from ..comm import native_store, PrefixStore
                 st = native_store()
-                comm = P2PCollectives(base.rank, base.world_size,
+                comm = P2PCollectives(base.rank, base.world_size, device=dev, overlap=True,
                                       store=PrefixStore("ddp_p2p", st) if st is not None else None)
             elif comm == "torch":
                 comm = base

@@ -1,4 +1,4 @@
-"""P2PAllReduce (one-shot all-reduce through IPC-mapped peer memory) with several processes on one GPU."""
+"""Peer-memory collectives (one-shot latency kernel, two-shot bandwidth kernel) with several processes on one GPU."""
 import os
 import socket
 import subprocess
@@ -65,6 +65,27 @@ def _start_ranks(worker, world):
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_allreduce_processes_on_one_gpu(world):
     _run_ranks(WORKER, world)
+
+
+def test_p2p_twoshot_single_rank():
+    import torch
+    from pytorch_distributed_amd.comm.p2p import P2PTwoShot
+    ar = P2PTwoShot(0, 1, store=None, cap_bytes=1 << 16)
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        t = torch.randn(50001, device="cuda").to(dtype)      # three pieces
+        ref = t.clone()
+        assert torch.equal(ar.all_reduce(t, "sum"), ref)
+        out = torch.empty_like(t)
+        assert torch.equal(ar.all_reduce(t, "avg", out=out), ref)
+    ar.check()
+    ar.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_p2p_twoshot_processes_on_one_gpu(world):
+    """Direct reduce-scatter + all-gather kernel: 1 element .. 3 region capacities, fp32 / fp16 / bf16, sum / avg,
+    in place / out of place vs an fp64 reference; all ranks end with identical bits."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "p2p2_worker.py"), world)
 
 
 def test_syncbn_statistics_over_p2p():
