@@ -320,10 +320,26 @@ def small_all_reduce(t: torch.Tensor, op: str = "sum", group=None) -> torch.Tens
             if op == "avg":
                 t /= nat.world_size
             return t
+    if t.is_cuda and not _has_device_backend(group):
+        # a host-only process group (gloo): stage through the host here rather than hand a device tensor to a
+        # backend whose device path is an afterthought (seen to stall with two ranks on one GPU)
+        h = t.detach().cpu()
+        dist.all_reduce(h, group=group)
+        if op == "avg":
+            h /= dist.get_world_size(group)
+        t.copy_(h)
+        return t
     dist.all_reduce(t, group=group)
     if op == "avg":
         t /= dist.get_world_size(group)
     return t
+
+
+def _has_device_backend(group=None) -> bool:
+    try:
+        return "nccl" in str(dist.get_backend_config(group)).lower()
+    except Exception:  # noqa: BLE001
+        return "nccl" in str(dist.get_backend(group)).lower()
 
 
 def get_rank() -> int:

@@ -131,6 +131,7 @@ def _bind(l):
         "pda_rccl_all_gather": ([c_p, c_p, c_p, c_ll, c_i, c_p, c_i], c_ll),
         "pda_rccl_reduce_scatter": ([c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_i], c_ll),
         "pda_rccl_all_reduce_group": ([c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i], c_ll),
+        "pda_rccl_sendrecv": ([c_p, c_p, c_ll, c_p, c_ll, c_i, c_i, c_p, c_i], c_ll),
         "pda_rccl_debug_state": ([c_p, ctypes.c_char_p, c_i], c_i),
         "pda_rccl_handoff_mode": ([c_p], c_i),
         "pda_rccl_async_error": ([c_p], c_i),
@@ -301,6 +302,15 @@ class RcclCommunicator:
         k = self._l.pda_rccl_reduce_scatter(self._h, t.data_ptr(), out.data_ptr(), out.numel(), _DT[t.dtype],
                                             _OPS[op], self._cur(), int(self.overlap))
         return self._done(k, "reduce_scatter", async_op, (t, out))
+
+    def sendrecv(self, send: torch.Tensor, recv: torch.Tensor, peer: int, async_op: bool = False,
+                 stream_ordered: bool = False):
+        """Send ``send`` to ``peer`` and receive ``recv`` from it (one RCCL group: ncclSend + ncclRecv)."""
+        send, recv = self._prep(send), self._prep(recv)
+        assert send.dtype == recv.dtype
+        k = self._l.pda_rccl_sendrecv(self._h, send.data_ptr(), send.numel(), recv.data_ptr(), recv.numel(),
+                                      _DT[send.dtype], int(peer), self._cur(), self._ov(stream_ordered))
+        return self._done(k, "sendrecv", async_op, (send, recv), stream_ordered)
 
     def barrier(self, timeout_s: float = 0.0) -> None:
         """All ranks have reached this point AND their previously enqueued device work is done.  With

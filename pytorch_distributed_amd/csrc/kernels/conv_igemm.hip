@@ -32,6 +32,8 @@ struct ConvArgs {
   // bnc = that layer's pre-normalisation tensor [M][Co].  With bn_scale/bn_shift the layer's ReLU mask
   // (bnc*scale+shift > 0) is applied to the output; with psum/psq the per-tile column sums of the final
   // output v and of v*bnc are written there (instead of the fprop statistics sum(y), sum(y^2)).
+  // fprop with bn_shift alone (bnc == nullptr): a per-output-channel bias added before the residual / ReLU
+  // (inference with BatchNorm folded into the weights: w' = w * scale, bias = shift).
   const void* bnc;
   const float* bn_scale;
   const float* bn_shift;
@@ -449,6 +451,21 @@ igemm_kernel(ConvArgs a) {
     float g1[EPC], g2[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { g1[e] = 0.f; g2[e] = 0.f; }
+    // folded-BatchNorm bias of this thread's 8 columns (fprop only; the column is the same for all its vectors)
+    const bool has_bias = !DGRAD && a.bn_shift != nullptr && a.bnc == nullptr;
+    float bs[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) bs[e] = 0.f;
+    if (has_bias) {
+      const int nc = n0 + (t % VPR) * EPC;
+      if (nc < a.Co) {
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bn_shift + nc + e);
+          bs[e] = b4.x; bs[e + 1] = b4.y; bs[e + 2] = b4.z; bs[e + 3] = b4.w;
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int v = t + NT * k;
@@ -463,6 +480,10 @@ igemm_kernel(ConvArgs a) {
       }
       if (ok) {
         Vec16<T> val = *reinterpret_cast<const Vec16<T>*>(lds + row * CP + cv * 16);
+        if (has_bias) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + bs[e]);
+        }
         if (Rz != nullptr) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e)
@@ -536,6 +557,7 @@ igemm_kernel(ConvArgs a) {
           }
           const bool ok = rok && (n < a.Co);
           const long long o = orow * a.Co + n;
+          if (!DGRAD && a.bn_shift != nullptr && a.bnc == nullptr && ok) v += a.bn_shift[n];
           if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
           if (a.relu) v = fmaxf(v, 0.f);
           if (Mk != nullptr && ok && !(ElemTraits<T>::to_f32(Mk[o]) > 0.f)) v = 0.f;

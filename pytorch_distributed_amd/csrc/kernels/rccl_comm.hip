@@ -45,6 +45,8 @@ struct Api {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -79,6 +81,8 @@ Api& api() {
     PDA_SYM(Broadcast, "ncclBroadcast")
     PDA_SYM(AllGather, "ncclAllGather")
     PDA_SYM(ReduceScatter, "ncclReduceScatter")
+    PDA_SYM(Send, "ncclSend")
+    PDA_SYM(Recv, "ncclRecv")
     PDA_SYM(GetErrorString, "ncclGetErrorString")
 #undef PDA_SYM
   });
@@ -382,6 +386,23 @@ PDA_EXPORT long long pda_rccl_reduce_scatter(void* h, const void* send, void* re
   if (!to_nccl_dtype(dtype, &dt) || !to_nccl_op(op, &ro) || count_per_rank < 0) return fail(c, "bad dtype/op/count");
   return issue(c, compute, overlap, [&](hipStream_t s) {
     return api().ReduceScatter(send, recv, (size_t)count_per_rank, dt, ro, c->comm, s); });
+}
+
+// Exchange with one peer: send `send_count` elements and receive `recv_count` in one RCCL group (what the
+// halving / doubling steps of Adasum need).
+PDA_EXPORT long long pda_rccl_sendrecv(void* h, const void* send, long long send_count, void* recv, long long recv_count,
+                                       int dtype, int peer, hipStream_t compute, int overlap) {
+  Comm* c = static_cast<Comm*>(h);
+  ncclDataType_t dt;
+  if (!to_nccl_dtype(dtype, &dt) || peer < 0 || peer >= c->world || send_count < 0 || recv_count < 0)
+    return fail(c, "bad dtype/peer/count");
+  return issue(c, compute, overlap, [&](hipStream_t s) {
+    ncclResult_t r = api().GroupStart();
+    if (r == ncclSuccess && send_count > 0) r = api().Send(send, (size_t)send_count, dt, peer, c->comm, s);
+    if (r == ncclSuccess && recv_count > 0) r = api().Recv(recv, (size_t)recv_count, dt, peer, c->comm, s);
+    const ncclResult_t e = api().GroupEnd();
+    return r != ncclSuccess ? r : e;
+  });
 }
 
 // Several all-reduces as ONE RCCL group launch (the buckets of a delayed / flushed backward).

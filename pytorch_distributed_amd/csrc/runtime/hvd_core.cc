@@ -45,7 +45,7 @@ int pda_shm_wait(void* h, long long ticket);
 
 namespace {
 
-enum Kind : int { K_ALLREDUCE = 0, K_BROADCAST = 1, K_ALLGATHER = 2 };
+enum Kind : int { K_ALLREDUCE = 0, K_BROADCAST = 1, K_ALLGATHER = 2, K_ADASUM = 3 };
 enum HOp : int { H_SUM = 0, H_PROD = 1, H_MIN = 2, H_MAX = 3, H_AVG = 4 };
 
 size_t dsize(int dt) {
@@ -246,6 +246,18 @@ class Engine {
     size_t i = 0;
     while (i < ready.size()) {
       Request& r = ready[i];
+      if (r.kind == K_ADASUM) {
+        // device tensors only (the python side reduces host tensors itself): the executor runs the
+        // halving / doubling exchange, one request at a time, in the negotiated order
+        if (r.device == 0) {
+          finish(r.handle, -1, "Adasum requests reach the engine for device tensors only");
+        } else {
+          std::vector<Request> g1{r};
+          run_device_group(g1);
+        }
+        ++i;
+        continue;
+      }
       if (r.kind == K_ALLGATHER) {
         if (r.device == 0) {
           int rc = pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, r.ptr, r.ptr_out, r.count * (long long)dsize(r.dtype)));

@@ -338,6 +338,20 @@ def _device_coll(dev):
     return TorchCollectives()
 
 
+class _InOrder:
+    """View of the native communicator whose collectives run on the caller's current stream."""
+
+    def __init__(self, c):
+        self._c = c
+        self.device_collectives = True
+
+    def all_gather(self, out, t):
+        return self._c.all_gather(out, t, stream_ordered=True)
+
+    def sendrecv(self, send, recv, peer):
+        return self._c.sendrecv(send, recv, peer, stream_ordered=True)
+
+
 def _fusion_buffer(dev, dtype, numel: int) -> torch.Tensor:
     key = (str(dev), dtype)
     buf = _S.fusion_bufs.get(key)
@@ -370,6 +384,10 @@ def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
                 for p in ps:
                     coll.all_gather(p.out, p.src, **kw)
                     launches += 1
+            elif kind == 3:
+                from .adasum import adasum_vhdd_
+                for p in ps:
+                    adasum_vhdd_(p.out, _InOrder(coll) if kw else coll, _S.info.rank, _S.info.world_size)
             else:
                 rname = {0: "sum", 1: "prod", 2: "min", 3: "max", 4: "sum"}[op_code]
                 post = ps[0].post * ((1.0 / _S.info.world_size) if op_code == 4 else 1.0)
@@ -433,6 +451,22 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
         p.done = True
         return _new_handle(p)
     if op == Adasum and kind == 0:
+        dense0 = out.is_contiguous() or (out.dim() == 4 and out.is_contiguous(memory_format=torch.channels_last))
+        if world & (world - 1):
+            raise NotImplementedError("Adasum needs a power-of-two number of ranks")
+        if (out.is_cuda and _S.engine is not None and dense0
+                and out.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+            # device tensors: the engine's executor runs the halving / doubling exchange (HIP dot / combine
+            # kernels), in the order negotiated with the other ranks like every other device collective
+            p.wire, p.ctx = out, None
+            p.event = torch.cuda.Event()
+            p.event.record(torch.cuda.current_stream(out.device))
+            eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), 3, out.data_ptr(), out.numel(), _DT[out.dtype], 0, 0,
+                                        1, 1.0, 1.0)
+            p.eh = int(eh)
+            with _S.lock:
+                _S.by_engine[p.eh] = p
+            return _new_handle(p)
         from .adasum import adasum_allreduce_
         adasum_allreduce_(out)
         p.done = True

@@ -231,14 +231,16 @@ class Dropout2d(Dropout):
 
 
 class Linear(tnn.Linear):
-    """Plain library GEMM (hipBLASLt through torch); computes in the activation dtype."""
+    """``torch.nn.Linear`` parameters, computed in the activation dtype on this package's MFMA GEMM kernels
+    (``ops/linear.py``: forward = 1x1 fprop, dX = dgrad with the class dimension zero-padded to the kernel's
+    K step, dW = split-K wgrad, db = column sums); the library GEMM only for shapes those kernels do not take."""
 
     def forward(self, x):
-        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
-        b = self.bias
-        if b is not None and b.dtype != x.dtype:
-            b = b.to(x.dtype)
-        return tnn.functional.linear(x, w, b)
+        from ..ops.linear import linear, LinearCache
+        cache = self.__dict__.get("_pda_cache")
+        if cache is None:
+            cache = self.__dict__["_pda_cache"] = LinearCache()
+        return linear(x, self.weight, self.bias, cache)
 
 
 class CrossEntropyLoss(tnn.Module):

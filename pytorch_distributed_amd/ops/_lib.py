@@ -74,6 +74,10 @@ _SIGS = {
     "pda_relu_cap_bwd": [c_i, c_p, c_p, c_p, c_ll, ctypes.c_float, c_p],
     "pda_add": [c_i, c_p, c_p, c_p, c_ll, c_i, c_p],
     "pda_add_n": [c_i, c_p, c_i, c_p, c_ll, c_p],
+    "pda_adasum_dots": [c_i, c_p, c_p, c_ll, c_p, c_p],
+    "pda_adasum_combine": [c_i, c_p, c_p, c_p, c_ll, c_p, c_i, c_i, c_p],
+    "pda_peer_bcast": [c_p, c_p, c_i, c_ll, c_p],
+    "pda_peer_enable": [c_i, c_i],
     "pda_bias_add": [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_colsum": [c_i, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_dropout": [c_i, c_p, c_p, c_ll, c_f, c_ull, c_ull, c_i, c_ll, c_i, c_p],

@@ -104,8 +104,10 @@ def make_weight(k: int, c: int, r: int, s: int, device=None, dtype=torch.float32
 # --------------------------------------------------------------------------- raw GPU launches
 def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pad: Tuple[int, int],
               res: Optional[torch.Tensor] = None, relu: bool = False, stats: bool = False, cfg: int = 0,
-              geom: Optional[tuple] = None, stats_buf: Optional[torch.Tensor] = None):
-    """y = conv(x, w) [+ res] [relu]; optionally also per-tile column sums for BatchNorm.
+              geom: Optional[tuple] = None, stats_buf: Optional[torch.Tensor] = None,
+              bias: Optional[torch.Tensor] = None):
+    """y = conv(x, w) [+ bias] [+ res] [relu]; optionally also per-tile column sums for BatchNorm.
+    ``bias``: fp32 ``[K]``, added in the GEMM epilogue (BatchNorm folded into the weights for inference).
 
     ``geom`` overrides the gather geometry ``(N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S)`` for inputs
     that are not plain NHWC (the padded 4-channel stem image).  ``stats_buf`` (fp32 ``[2, slots, K]``,
@@ -126,7 +128,7 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     if cfg == 0 and backends.benchmark and geom is None:
         cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats),
                          _FPROP_CFGS if res is None else _DGRAD_EX_CFGS,
-                         lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None))
+                         lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias))
     cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
     y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
     psum = psq = None
@@ -140,8 +142,10 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
         else:
             part = torch.empty((2, tiles_m, K), device=x.device, dtype=torch.float32)
             psum, psq = part[0], part[1]
-    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0, 0, 0, 0,
-                          _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K or not bias.is_contiguous()):
+        raise ValueError("fprop_gpu: bias must be a contiguous fp32 [K] tensor")
+    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0, 0, 0,
+                          _lib.ptr(bias), _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
                           stride[0], stride[1], pad[0], pad[1], int(relu), cfg, slots, _lib.stream())
     if rc < 0:
         return None  # shape not covered by the MFMA kernels
@@ -301,7 +305,7 @@ class WeightCache:
     only when the parameter has changed (torch version counter or our optimizer's
     generation counter)."""
 
-    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "stats", "__weakref__")
+    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "stats", "key_fold", "fold", "__weakref__")
 
     STAT_SLOTS = 64
 
@@ -322,6 +326,8 @@ class WeightCache:
         self.pinned_lp = None  # (dtype, tensor, torch version) kept current by the optimizer kernel (amp O2)
         self.key_lp = None
         self.lp = None
+        self.key_fold = None   # inference: weights with the BatchNorm scale folded in, and the matching bias
+        self.fold = None
         self.key_t = None
         self.t = None
         self.t_weight = None   # weakref to the parameter the transpose in ``t`` belongs to
@@ -349,6 +355,19 @@ class WeightCache:
             self.lp = w.to(dtype)
             self.key_lp = key
         return self.lp
+
+    def folded(self, weight: torch.Tensor, dtype: torch.dtype, versions, coeffs):
+        """``(w * scale[k]) in dtype, shift``: eval-mode BatchNorm folded into the conv
+        (``y = conv(x, w) * scale + shift == conv(x, w * scale) + shift``).  ``coeffs()`` returns the fp32
+        ``(scale, shift)``; ``versions`` identifies the state they depend on - the pair is rebuilt only when
+        that or the weight moved."""
+        key = self._key(weight, dtype) + tuple(versions)
+        if self.key_fold != key:
+            scale, shift = coeffs()
+            w = krsc(weight.detach()).float()
+            self.fold = ((w * scale.view(-1, 1, 1, 1)).to(dtype).contiguous(), shift.float().contiguous())
+            self.key_fold = key
+        return self.fold
 
     def transposed(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         key = self._key(weight, dtype)

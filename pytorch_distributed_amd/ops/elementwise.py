@@ -121,7 +121,9 @@ def add_n(tensors, out: torch.Tensor = None) -> torch.Tensor:
     GPU: one launch of ``add_n_kernel``; CPU: plain adds.  No autograd."""
     import ctypes
     ts = list(tensors)
-    assert ts and all(t.shape == ts[0].shape and t.dtype == ts[0].dtype and t.device == ts[0].device for t in ts)
+    # (sources may live on other GPUs: the kernel runs on out's device and reads them through peer mappings)
+    assert ts and all(t.shape == ts[0].shape and t.dtype == ts[0].dtype and t.device.type == ts[0].device.type
+                      for t in ts)
     if out is None:
         out = torch.empty_like(ts[0])
     if not ts[0].is_cuda:
@@ -137,5 +139,7 @@ def add_n(tensors, out: torch.Tensor = None) -> torch.Tensor:
     ts = [t if t.is_contiguous() else t.contiguous() for t in ts]
     l = _lib.lib()
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    _lib.check(l.pda_add_n(_lib.dt(ts[0]), arr, len(ts), out.data_ptr(), ts[0].numel(), _lib.stream()), "pda_add_n")
+    with torch.cuda.device(out.device):       # the kernel runs where the result lives
+        _lib.check(l.pda_add_n(_lib.dt(ts[0]), arr, len(ts), out.data_ptr(), ts[0].numel(),
+                               torch.cuda.current_stream(out.device).cuda_stream), "pda_add_n")
     return out

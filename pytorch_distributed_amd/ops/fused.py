@@ -31,6 +31,24 @@ from . import _lib, conv as C, norm as Nm, pool as P
 _SUMS_MIN_K = int(os.environ.get("PDA_FUSE_BN_SUMS_MIN_K", "0"))
 
 
+# Inference (no_grad + eval): BatchNorm's running-statistics affine is folded into the cached low-precision
+# weights and the GEMM epilogue adds the bias, the residual and the ReLU: one kernel per conv+BN(+add)(+ReLU),
+# no normalisation pass.  PDA_FOLD_EVAL_BN=0 keeps the two-pass form.
+_FOLD_EVAL_BN = os.environ.get("PDA_FOLD_EVAL_BN", "1") == "1"
+
+
+def _conv_folded_bn(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNState, cache: C.WeightCache):
+    x = x.contiguous()
+    K = weight.shape[0]
+    if K % (16 // x.element_size()) != 0:
+        return None                                  # the bias lives in the vector write-out
+    vers = tuple(t._version if t is not None else -1 for t in (gamma, beta, st.running_mean, st.running_var))
+    vers += (Nm.stats_generation(), st.running_mean.data_ptr(), float(st.eps))
+    w_f, b_f = cache.folded(weight, x.dtype, vers, lambda: Nm.eval_coeffs(gamma, beta, st))
+    res = residual.contiguous() if residual is not None else None
+    return C.fprop_gpu(x, w_f, stride, pad, res=res, relu=relu, bias=b_f)
+
+
 class BNBackwardLink:
     """Hand-off between a fused op (the producer) and the ONE fused op that consumes its output.
 
@@ -214,6 +232,11 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: N
         y = C.conv2d_ref(x, weight, None, stride, pad)
         o = Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
         return (o, x) if passthrough else o
+    if not torch.is_grad_enabled() and not st.training and st.running_mean is not None and _FOLD_EVAL_BN:
+        o = _conv_folded_bn(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
+                            cache or C.WeightCache())
+        if o is not None:
+            return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
                               cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link)
 

@@ -66,6 +66,13 @@ def compress_partials(pa: torch.Tensor, pb: torch.Tensor):
     return out[0], out[1]
 
 
+_STATS_GENERATION = 0   # bumped whenever a kernel rewrites running statistics (their torch version counters do not move)
+
+
+def stats_generation() -> int:
+    return _STATS_GENERATION
+
+
 def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = False):
     """partials -> (mean, invstd, scale, shift); updates running stats in place.
 
@@ -93,6 +100,9 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = Fa
     out = torch.empty((4, C), device=dev, dtype=torch.float32)
     rm = st.running_mean if (st.training and st.running_mean is not None) else None
     rv = st.running_var if (st.training and st.running_var is not None) else None
+    if rm is not None:
+        global _STATS_GENERATION
+        _STATS_GENERATION += 1
     mom = st.momentum
     nbt = None
     if st.num_batches_tracked is not None and st.training:

@@ -6,14 +6,18 @@ The reference's first launch style, ``nn.DataParallel(model, device_ids=gpus, ou
 1. *scatter*   - the batch is chunked along ``dim`` and each chunk is copied to its device over
    xGMI peer-to-peer on a per-device copy stream (``wait_stream`` + ``record_stream`` hand-off);
 2. *replicate* - parameters and buffers of the master copy (on ``device_ids[0]``) are packed into
-   one flat buffer per dtype (one multi-tensor launch), the flat buffer is copied once per peer
-   device, and every replica's tensors are *views* of its device's buffer (no unflatten copies);
+   one flat buffer per dtype (one multi-tensor launch); ONE kernel on the master device then stores
+   the buffer into every replica's device over xGMI peer access (``csrc/kernels/peer.hip``: the source
+   is read once, all outbound links carry data at the same time), and every replica's tensors are
+   *views* of its device's buffer (no unflatten copies);
 3. *parallel_apply* - one python thread per replica, each bound to its device;
 4. *gather*    - outputs are copied to ``output_device`` and concatenated.
 
 Backward is autograd through the same graph: the replicate node's backward is the
-reduce-add of every replica's flat gradient buffer onto the master device (one peer copy per
-device + one multi-tensor ``axpby`` accumulation), i.e. torch's ``ReduceAddCoalesced``.
+reduce-add of every replica's flat gradient buffer onto the master device - one N-way ``add_n``
+launch on the master that reads the replicas' buffers directly through their peer mappings (no
+staging copies) - i.e. torch's ``ReduceAddCoalesced``.  Device pairs without a peer path (and CPU
+"devices") take runtime copies instead.
 As upstream, BatchNorm statistics are per replica and only replica 0 (the master module itself)
 keeps its running statistics.  Devices may be repeated or be ``"cpu"``, which is how the CPU
 test-suite exercises the whole path without GPUs.
@@ -53,6 +57,55 @@ def _copy_stream(dev: torch.device):
     if dev not in _COPY_STREAMS:
         _COPY_STREAMS[dev] = torch.cuda.Stream(dev)
     return _COPY_STREAMS[dev]
+
+
+_PEER_OK: Dict[tuple, bool] = {}
+
+
+def _peer_ok(a: torch.device, b: torch.device) -> bool:
+    """Kernels running on ``a`` may dereference pointers into ``b``'s memory (peer access enabled on demand)."""
+    if a.type != "cuda" or b.type != "cuda":
+        return False
+    ia = a.index if a.index is not None else torch.cuda.current_device()
+    ib = b.index if b.index is not None else torch.cuda.current_device()
+    key = (ia, ib)
+    if key not in _PEER_OK:
+        from ..ops import _lib
+        torch.cuda.init()
+        _PEER_OK[key] = _lib.lib().pda_peer_enable(ia, ib) == 0
+    return _PEER_OK[key]
+
+
+def _peer_broadcast(flat: torch.Tensor, devices: Sequence[torch.device]) -> Optional[List[torch.Tensor]]:
+    """``flat`` (on its own device) -> one copy per entry of ``devices`` with a single direct-store kernel;
+    None when some pair has no peer path (the caller copies through the runtime then)."""
+    import ctypes
+    from ..ops import _lib
+    src = flat.device
+    if src.type != "cuda" or not all(_peer_ok(src, d) for d in devices):
+        return None
+    outs, ptrs = [], []
+    for d in devices:
+        if d == src:
+            outs.append(flat)
+        else:
+            o = torch.empty_like(flat, device=d)
+            outs.append(o)
+            ptrs.append(o.data_ptr())
+    for k in range(0, len(ptrs), 8):
+        part = ptrs[k:k + 8]
+        arr = (ctypes.c_void_p * len(part))(*part)
+        with torch.cuda.device(src):
+            _lib.check(_lib.lib().pda_peer_bcast(flat.data_ptr(), arr, len(part), flat.numel() * flat.element_size(),
+                                                 torch.cuda.current_stream(src).cuda_stream), "pda_peer_bcast")
+    if ptrs:
+        # the replicas' streams must not read their copy before the store kernel has finished
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(src))
+        for d in set(devices):
+            if d != src:
+                torch.cuda.current_stream(d).wait_event(ev)
+    return outs
 
 
 def scatter(tensor: torch.Tensor, devices: Sequence, dim: int = 0) -> List[torch.Tensor]:
@@ -122,8 +175,12 @@ def broadcast_coalesced(tensors: Sequence[torch.Tensor], devices: Sequence) -> L
         srcs = [_physical_flat(tensors[i].detach()) if _is_dense(tensors[i]) else tensors[i].detach().reshape(-1)
                 for i in idxs]
         flat = mt.flatten(srcs) if dt in (torch.float32, torch.float16, torch.bfloat16) else torch.cat(srcs)
+        direct = _peer_broadcast(flat, devices) if flat.is_cuda and flat.data_ptr() % 16 == 0 else None
         for di, d in enumerate(devices):
-            fd = flat if di == 0 and flat.device == d else flat.to(d, non_blocking=True)
+            if direct is not None:
+                fd = direct[di]
+            else:
+                fd = flat if di == 0 and flat.device == d else flat.to(d, non_blocking=True)
             off = 0
             for i in idxs:
                 t = tensors[i]
@@ -157,7 +214,16 @@ def reduce_add_coalesced(per_device: Sequence[Sequence[torch.Tensor]], target) -
     flats = []
     for lst in per_device[1:]:
         flat = mt.flatten([flat_like(t, r) for t, r in zip(lst, first)])
-        flats.append(flat.to(target, non_blocking=True))   # one peer copy per replica (xGMI)
+        if flat.device != target and _peer_ok(target, flat.device) and flat.data_ptr() % 16 == 0:
+            # leave it where it is: the reduce kernel on the target reads it through the peer mapping, once the
+            # replica's stream has produced it
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(flat.device))
+            torch.cuda.current_stream(target).wait_event(ev)
+            flat.record_stream(torch.cuda.current_stream(target))
+            flats.append(flat)
+        else:
+            flats.append(flat.to(target, non_blocking=True))   # no peer path: one runtime copy per replica
     if flats and acc.is_cuda and acc.dtype in (torch.float32, torch.float16, torch.bfloat16):
         from ..ops.elementwise import add_n
         add_n([acc] + flats, out=acc)                        # N-way reduce-add: every buffer is read once

@@ -850,3 +850,135 @@ def test_kernel_library_is_loaded():
     _lib.lib()
     maps = open("/proc/self/maps").read()
     assert "libpda_kernels.so" in maps
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_linear_runs_on_the_conv_gemm_kernels(dtype):
+    """nn.Linear forward / dX / dW / db on fprop / dgrad (class dimension zero-padded) / wgrad / colsum vs an fp32
+    reference on the same (rounded) inputs; shapes: the ResNet head, the MNIST fc1, a batch that is no tile multiple."""
+    from pytorch_distributed_amd.ops import linear as L
+    from pytorch_distributed_amd import nn as pnn
+    torch.manual_seed(61)
+    tol = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
+    for B, K, N in ((64, 2048, 1000), (33, 320, 48), (400, 512, 1000)):
+        lin = pnn.Linear(K, N).to(DEV)
+        x = torch.randn(B, K, device=DEV).to(dtype).requires_grad_(True)
+        assert L.supported(x, lin.weight), (B, K, N, dtype)
+        g = torch.randn(B, N, device=DEV).to(dtype)
+        y = lin(x)
+        assert y.dtype == dtype and y.shape == (B, N)
+        y.backward(g)
+        wq = lin.weight.detach().to(dtype).float()
+        xr = x.detach().float().requires_grad_(True)
+        wr = wq.clone().requires_grad_(True)
+        br = lin.bias.detach().float().clone().requires_grad_(True)
+        yr = F.linear(xr, wr, br)
+        yr.backward(g.float())
+        assert rel_err(y.float(), yr) < tol, (B, K, N, "y")
+        assert rel_err(x.grad.float(), xr.grad) < tol, (B, K, N, "dx")
+        assert rel_err(lin.weight.grad.float(), wr.grad) < tol, (B, K, N, "dw")
+        assert rel_err(lin.bias.grad.float(), br.grad) < tol, (B, K, N, "db")
+    # a reduction length the MFMA kernels do not step through falls back to the library GEMM and still works
+    lin = pnn.Linear(50, 10).to(DEV)
+    x = torch.randn(7, 50, device=DEV)
+    assert not L.supported(x, lin.weight)
+    assert rel_err(lin(x), F.linear(x, lin.weight, lin.bias)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_eval_batchnorm_folded_into_conv_matches_two_pass(dtype, monkeypatch):
+    """Inference (eval + no_grad): BatchNorm folded into the cached weights, bias / residual / ReLU in the GEMM
+    epilogue == conv followed by the normalisation pass; the fold follows later training steps."""
+    from pytorch_distributed_amd.ops import fused
+    torch.manual_seed(62)
+    m = models.get_model("resnet50", num_classes=10).to(DEV)
+    if dtype != torch.float32:
+        m.set_compute_dtype(dtype)
+    x = torch.randn(8, 3, 64, 64, device=DEV)
+    for _ in range(2):      # give the running statistics something to hold
+        m.train()
+        m(x).float().sum().backward()
+    m.eval()
+    with torch.no_grad():
+        monkeypatch.setattr(fused, "_FOLD_EVAL_BN", False)
+        ref = m(x).float()
+        monkeypatch.setattr(fused, "_FOLD_EVAL_BN", True)
+        out = m(x).float()
+        assert rel_err(out, ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+        # running statistics change (a training forward): the cached fold must not be reused
+        m.train()
+        with torch.enable_grad():
+            m(x * 3 + 1).float().sum().backward()
+        m.eval()
+        monkeypatch.setattr(fused, "_FOLD_EVAL_BN", False)
+        ref2 = m(x).float()
+        monkeypatch.setattr(fused, "_FOLD_EVAL_BN", True)
+        out2 = m(x).float()
+        assert rel_err(out2, ref2) < (1e-4 if dtype == torch.float32 else 2e-2)
+        assert rel_err(ref2, ref) > 1e-3      # the statistics really moved
+
+
+def test_peer_broadcast_and_direct_reduce_kernels_single_device():
+    """DataParallel's device-side copies: the direct-store broadcast kernel (one read, N stores) and the N-way
+    reduce-add reading its sources through peer pointers - here all "peers" are this GPU."""
+    import ctypes
+    from pytorch_distributed_amd.parallel import data_parallel as dp
+    torch.manual_seed(63)
+    for nbytes in (16, 4096 + 16, (1 << 20) + 7):
+        src = torch.randint(0, 256, (nbytes,), device=DEV, dtype=torch.uint8)
+        dsts = [torch.zeros_like(src) for _ in range(3)]
+        arr = (ctypes.c_void_p * 3)(*[d.data_ptr() for d in dsts])
+        _lib.check(_lib.lib().pda_peer_bcast(src.data_ptr(), arr, 3, nbytes, _lib.stream()), "pda_peer_bcast")
+        assert all(torch.equal(d, src) for d in dsts)
+    assert dp._peer_ok(torch.device(DEV, 0), torch.device(DEV, 0))
+    params = [torch.randn(64, 3, 3, 3, device=DEV), torch.randn(17, device=DEV), torch.randn(5, 4, device=DEV).half()]
+    copies = dp.broadcast_coalesced(params, [torch.device(DEV, 0)] * 3)
+    for rep in copies:
+        for c, p in zip(rep, params):
+            assert torch.equal(c, p)
+
+
+def test_resnet50_bench_configuration_parity_224_b64():
+    """The benchmark's own configuration at a smaller batch: 224x224, fp16 O2, backends.benchmark=True (the
+    per-shape tile auto-tuner picks among all tile sets, 256x128 included), fused optimizer.  First-step loss and
+    the gradients of a few layers against the stock PyTorch model (fp32 oracle; stock autocast fp16 as yardstick
+    for what fp16 can deliver on a random-init ResNet-50)."""
+    from pytorch_distributed_amd import amp, backends
+    from pytorch_distributed_amd.optim import FusedSGD
+    torch.manual_seed(64)
+    old = backends.benchmark
+    backends.benchmark = True
+    try:
+        m = models.get_model("resnet50").to(DEV)
+        ref = models.torch_resnet("resnet50").to(DEV)
+        ref.load_state_dict(m.state_dict())
+        opt = FusedSGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        m, opt = amp.initialize(m, opt, opt_level="O2", loss_scale=1024.0, verbosity=0)
+        x = torch.randn(64, 3, 224, 224, device=DEV)
+        t = torch.randint(0, 1000, (64,), device=DEV)
+        for _ in range(2):                       # first pass tunes, second pass runs the chosen tiles
+            opt.zero_grad(set_to_none=False)
+            loss = ops.cross_entropy(m(x), t)
+            with amp.scale_loss(loss, opt) as scaled:
+                scaled.backward()
+        ref.train()
+        lr = F.cross_entropy(ref(x), t)
+        (lr * 1024.0).backward()
+        assert abs(loss.item() - lr.item()) < 5e-2 * lr.item(), (loss.item(), lr.item())
+        g, gr = dict(m.named_parameters()), dict(ref.named_parameters())
+        names = ["fc.weight", "fc.bias", "layer4.2.conv3.weight", "layer3.5.conv2.weight", "layer1.0.conv1.weight",
+                 "conv1.weight"]
+        ours = {k: _cos(g[k].grad, gr[k].grad) for k in names}
+        orc = {k: gr[k].grad.detach().clone() for k in names}
+        ref.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            la = F.cross_entropy(ref(x), t)
+        (la * 1024.0).backward()
+        stock = {k: _cos(gr[k].grad, orc[k]) for k in names}
+        assert ours["fc.weight"] > 0.99 and ours["fc.bias"] > 0.99, ours
+        for k in names:
+            assert ours[k] > stock[k] - 0.1, (k, ours, stock)
+        opt.step()
+        assert opt._amp_scaler_ref.skipped_steps() == 0
+    finally:
+        backends.benchmark = old

@@ -33,11 +33,11 @@ def test_p2p_allreduce_single_rank():
     ar.close()
 
 
-def _run_ranks(worker, world, attempts=3):
+def _run_ranks(worker, world, attempts=3, extra=()):
     """Start `world` ranks; a rendezvous port that somebody else grabbed between probing and binding is
     the one failure worth a second try."""
     for attempt in range(attempts):
-        procs, outs = _start_ranks(worker, world)
+        procs, outs = _start_ranks(worker, world, extra)
         if attempt + 1 < attempts and any("rendezvous store" in o for o in outs):
             continue
         break
@@ -45,10 +45,10 @@ def _run_ranks(worker, world, attempts=3):
         assert p.returncode == 0 and f"rank {r}: OK" in o, (r, o[-2000:])
 
 
-def _start_ranks(worker, world):
+def _start_ranks(worker, world, extra=()):
     port = _free_port()
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port)], env=env,
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), *extra], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     try:
@@ -106,6 +106,17 @@ def test_ddp_ranks_on_one_gpu_match_full_batch(world):
     _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), world)
 
 
-def test_hvd_optimizer_two_ranks_on_one_gpu():
-    """hvd.DistributedOptimizer over device tensors, engine collectives through the peer-memory backend."""
-    _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), 2)
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddp_o2_fused_fp16_wire_ranks_on_one_gpu(world):
+    """amp O2 + DDP with per-rank different initial weights: the optimizer-maintained half copies follow the
+    parameter broadcast, gradients travel as fp16 (pre-divided by the world size) through the two-shot kernel
+    on its own stream and FusedSGD consumes them from the wire buckets; first updates == full-batch reference."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_p2p_worker.py"), world, extra=("O2",))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hvd_optimizer_ranks_on_one_gpu(world):
+    """hvd.DistributedOptimizer over device tensors, engine collectives through the peer-memory backend: fused
+    pack/cast/unpack groups (<= 3 launches each), a real all-gather, and device Adasum (halving / doubling with
+    the HIP dot / combine kernels) against the fp64 host tree."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), world)

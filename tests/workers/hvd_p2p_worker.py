@@ -49,7 +49,22 @@ def main():
         dr = torch.cat([(q.detach() - a).flatten() for q, a in zip(ref.parameters(), w0)])
         upd = max(upd, ((du - dr).norm() / dr.norm()).item())
     avg = hvd.allreduce(torch.tensor([float(rank + 1)], device=dev), name="probe").item()
-    ok = start == 0.0 and upd < 5e-3 and abs(avg - (world + 1) / 2) < 1e-6
+    gath = hvd.allgather(torch.full((2, 3), float(rank), device=dev), name="g")
+    gath_ok = gath.shape == (2 * world, 3) and all(float(gath[2 * r, 0]) == r for r in range(world))
+    # device Adasum (halving / doubling exchange + HIP dot / combine kernels) against the fp64 tree on the host
+    from pytorch_distributed_amd.hvd.adasum import adasum_tree
+    g = torch.Generator().manual_seed(77)
+    vecs = [torch.randn(10007, generator=g) for _ in range(world)]
+    vecs[1 % world] = vecs[1 % world] + 0.5 * vecs[0]            # correlated gradients: the coefficients matter
+    ada = hvd.allreduce(vecs[rank].to(dev), op=hvd.Adasum, name="ada")
+    ada_ref = adasum_tree(vecs)
+    ada_err = ((ada.cpu().double() - ada_ref.double()).norm() / ada_ref.double().norm()).item()
+    st = hvd.engine_stats()
+    # a fused device group costs one pack(+cast to fp16), one collective and one unpack(+cast back, average)
+    launches_ok = st["device_groups"] > 0 and st["max_launches_per_group"] <= 3
+    ok = (start == 0.0 and upd < 5e-3 and abs(avg - (world + 1) / 2) < 1e-6 and gath_ok and launches_ok
+          and ada_err < 1e-5)
+    print(f"rank {rank}: engine {st} allgather_ok {gath_ok} adasum rel err {ada_err:.2e}", flush=True)
     print(f"rank {rank}: {'OK' if ok else 'FAILED'} initial diff {start:.1e}, update rel err {upd:.2e}, avg {avg}", flush=True)
     hvd.shutdown()
     return 0 if ok else 1
