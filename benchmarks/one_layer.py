@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--res", action="store_true")
+    ap.add_argument("--warmup", type=int, default=0, help="untimed launches first (0 for profiler runs)")
+    ap.add_argument("--no-stats", action="store_true", help="fprop without the BatchNorm statistics epilogue")
     a = ap.parse_args()
     dt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": torch.float32}[a.dtype]
     dev = "cuda"
@@ -38,19 +40,24 @@ def main():
     dy = torch.randn(a.batch, ho, ho, a.cout, device=dev).to(dt)
     res = torch.randn_like(x) if a.res else None
     dw = torch.zeros(a.cout, k, k, a.cin, device=dev)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters):
+    def run():
         if a.op == "fprop":
-            C.fprop_gpu(x, w, (s, s), (pad, pad), stats=True, cfg=a.cfg)
+            C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=a.cfg)
         elif a.op == "dgrad":
             C.dgrad_gpu(dy, wt, (a.h, a.h), (s, s), (pad, pad), res=res, cfg=a.cfg)
         else:
             C.wgrad_gpu(dy, x, k, k, (s, s), (pad, pad), cfg=a.cfg, nsplit=a.nsplit, out=dw)
+
+    for _ in range(a.warmup):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        run()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{a.op} cfg={a.cfg}: {e0.elapsed_time(e1) * 1e3 / a.iters:.1f} us/iter (first iterations include warm-up)")
+    print(f"{a.op} cfg={a.cfg}: {e0.elapsed_time(e1) * 1e3 / a.iters:.1f} us/iter after {a.warmup} warm-up launches")
 
 
 if __name__ == "__main__":

@@ -19,7 +19,9 @@
 // fragment reads are bank-conflict free.  wgrad reduces over pixels, which is
 // the strided dimension of both operands, so its fragments come from
 // ds_read_b64_tr_b16 (hardware transposing LDS read) for the 16-bit types.
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 struct ConvArgs {
@@ -51,6 +53,10 @@ struct ConvArgs {
   int stat_slots;        // 0: psum/psq hold one row per M tile; n > 0: n rows, float-atomic accumulated
   int r_lo, r_hi, s_lo, s_hi;  // taps that can touch a real pixel for at least one row (host-computed):
                                // on tiny feature maps (3x3 conv on a 1x1 or 2x2 map) most taps only see padding
+  unsigned tap_pattern_h, tap_pattern_w;  // dgrad: bit k*stride set for every k (taps congruent to 0 mod stride)
+  unsigned long long* stamps;              // diagnostics (PDA_IGEMM_STAMPS=1): 8 s_memtime stamps per workgroup
+  int ablate;                              // diagnostics (PDA_IGEMM_ABLATE), bits: 1 = no operand loads after the
+                                           // prologue, 2 = no fragment reads / MFMAs, 4 = no epilogue (results are garbage either way)
 };
 
 // MODE 0: fprop.  MODE 1: dgrad, any power-of-two stride: every tap is visited and rows whose tap
@@ -85,16 +91,29 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 
 // Two waves per SIMD: the 128x128 tile sits right at the 256-register limit, and without the hint
 // the stride-2 dgrad variant tips over it and runs at half the occupancy.
+// Diagnostic builds (-DPDA_IGEMM_DIAG) honour ConvArgs::ablate; production builds compile the checks away.
+#ifdef PDA_IGEMM_DIAG
+#define PDA_ABL(bit_) ((a.ablate & (bit_)) != 0)
+#else
+#define PDA_ABL(bit_) false
+#endif
 #ifndef PDA_IGEMM_ATTR
 #define PDA_IGEMM_ATTR __attribute__((amdgpu_waves_per_eu(2)))
 #endif
 // EX: the epilogue extras (res, mask, bnc) are compiled in; the plain instantiation keeps the lean
 // write-out (the extras cost registers and scalar state even when their pointers are null).
-template <typename T, int BM, int BN, int ROWB, int MODE, bool EX>
-__global__ void __launch_bounds__(256) PDA_IGEMM_ATTR
+// WM: waves along M (WM x 2 waves per workgroup).  STAGES = 0: register-staged operand tiles, two LDS
+// buffers (the loads of step t+1 are issued before the MFMAs of step t and written to LDS after them).
+// STAGES >= 3 (16-bit types): a ring of STAGES LDS buffers filled by LDS-DMA (buffer_load ... lds): the
+// operands never pass through registers, the tile of step t+2 is requested while step t computes, and the
+// only per-step synchronisation is one counted vmcnt + one barrier (see the main loop).
+template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0>
+__global__ void __launch_bounds__(128 * WM) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
-  constexpr int WM = 2;                    // 2 x 2 waves; a 256-row tile gives each wave 128 x 64 outputs
   constexpr int NT = 128 * WM;             // threads per workgroup
+  constexpr bool DMA = STAGES > 0;
+  constexpr int NST = DMA ? STAGES : 2;    // LDS buffers per operand
+  static_assert(!DMA || (sizeof(T) == 2 && STAGES >= 3 && STAGES <= 4), "LDS-DMA ring: 16-bit operands, 3-4 buffers");
   constexpr bool DGRAD = MODE != MODE_FPROP;
   constexpr bool PAR = MODE == MODE_DGRAD_S2;
   constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
@@ -108,18 +127,25 @@ igemm_kernel(ConvArgs a) {
   static_assert(MI >= 1 && NI >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
 
   // operand tiles (two stages); the 16-bit epilogue re-uses the space to stage the output tile
-  constexpr int TILE_BYTES = 2 * (BM + BN) * ROWB;
+  constexpr int TILE_BYTES = NST * (BM + BN) * ROWB;
   constexpr int EPI_BYTES = sizeof(T) == 2 ? BM * (BN * (int)sizeof(T) + 16) : 0;
   constexpr int GRED_BYTES = (EX && sizeof(T) == 2) ? 2 * EPC * (NT + 8) * 4 : 0;  // BatchNorm-backward sums
   constexpr int LDS_BYTES0 = TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES0 > GRED_BYTES ? LDS_BYTES0 : GRED_BYTES];
   unsigned char* ldsA = lds;
-  unsigned char* ldsB = lds + 2 * BM * ROWB;
+  unsigned char* ldsB = lds + NST * BM * ROWB;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int l31 = lane & 31, lh = lane >> 5;
+  // diagnostics: shader-clock stamps of this workgroup's phases (thread 0 only; a.stamps is null in normal runs)
+#define PDA_STAMP(i_)                                                                                \
+  do {                                                                                               \
+    if (a.stamps != nullptr && t == 0 && blockIdx.x < 8192)                                          \
+      a.stamps[blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();                                \
+  } while (0)
+  PDA_STAMP(0);
 
   const int tiles_n = (a.Co + BN - 1) / BN;
   const int tiles_m = (a.M + BM - 1) / BM;
@@ -164,35 +190,69 @@ igemm_kernel(ConvArgs a) {
     return m < a.M;
   };
 
-  // per-thread A rows: decompose m once, it does not change along K
-  long long abase[A_IT];
-  int ah0[A_IT], aw0[A_IT];
+  // ---- operand addressing: buffer loads, 32-bit per-lane offset + wave-uniform scalar offset ----
+  // Nothing about a thread's A rows changes along K except the tap (r, s) and the channel offset, and both
+  // are wave-uniform: per row the thread keeps ONE byte offset (its pixel, relative to the first image of
+  // the tile) and two bit masks (which r / which s land on a real pixel); the tap and channel terms ride in
+  // the scalar offset of the load.  A tap that only sees padding (or a row past M) swaps the row offset for
+  // one past the descriptor's range and the hardware returns zeros: no branch around the load, no 64-bit
+  // address arithmetic in the loop, and a new select only when the tap changes.
+  constexpr unsigned OOB = 0x80000000u;      // >= num_records of the descriptors below
+  constexpr int ES = (int)sizeof(T);
+  const int n_first = m0 / row_hw;           // first image this tile touches (wave-uniform)
+  // scaled strides: a dgrad tap r moves the gathered dY pixel by -r/stride rows (only taps with an exact
+  // quotient are live, see the masks), which is linear in r because sh, sw are multiples of the stride
+  const long long shs = DGRAD ? (a.sh >> a.sh_log2) : a.sh;
+  const long long sws = DGRAD ? (a.sw >> a.sw_log2) : a.sw;
+  // the descriptor base sits before the tile's first image by the largest negative tap displacement, so
+  // every per-lane offset and every scalar offset is non-negative
+  const long long bias_el = DGRAD ? (long long)(a.R - 1) * shs + (long long)(a.S - 1) * sws
+                                  : (long long)a.pad_h * a.sh + (long long)a.pad_w * a.sw;
+  const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(X) + ((long long)n_first * a.sn - bias_el), 0, 0x7fffffff, 0x00020000);
+  const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(Wt) + (long long)n0 * Ktot, 0, 0x7fffffff, 0x00020000);
+
+  // LDS-DMA writes lane-linear (wave base + 16 * lane): the chunk swizzle of the LDS image moves to the
+  // SOURCE side, i.e. the lane that fills chunk slot kc of a row fetches logical chunk kc ^ swz(row)
+  // (the same for every pass of a thread: a pass moves on by a multiple of the swizzle period)
+  static_assert(!DMA || (RPT % (CPR * (256 / ROWB)) == 0), "swizzle must repeat with the pass stride");
+  const int kcs = DMA ? (kc ^ swz<ROWB>(trow)) : kc;
+  unsigned apix[A_IT], ahm[A_IT], awm[A_IT];
+  auto range_mask = [](int lo, int hi) -> unsigned {  // bits lo..hi (inclusive), empty when hi < lo
+    return hi >= lo ? ((2u << hi) - (1u << lo)) : 0u;
+  };
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + trow + i * RPT;
     int n, ho, wo;
     if (decode(m, n, ho, wo)) {
-      abase[i] = (long long)n * a.sn + kc * EPC;
+      const long long img = (long long)(n - n_first) * a.sn + kcs * EPC;
       if (DGRAD) {
-        ah0[i] = ho + a.pad_h;
-        aw0[i] = wo + a.pad_w;
+        // live taps: 0 <= h + pad - r <= (Hi - 1) * stride and (h + pad - r) divisible by the stride
+        const int ah = ho + a.pad_h, aw = wo + a.pad_w;
+        apix[i] = (unsigned)((img + (long long)ah * shs + (long long)aw * sws) * ES);
+        ahm[i] = range_mask(max(0, ah - (a.Hi - 1) * a.stride_h), min(a.R - 1, ah)) &
+                 (a.tap_pattern_h << (ah & (a.stride_h - 1)));
+        awm[i] = range_mask(max(0, aw - (a.Wi - 1) * a.stride_w), min(a.S - 1, aw)) &
+                 (a.tap_pattern_w << (aw & (a.stride_w - 1)));
       } else {
-        ah0[i] = ho * a.stride_h - a.pad_h;
-        aw0[i] = wo * a.stride_w - a.pad_w;
+        const int h0 = ho * a.stride_h, w0 = wo * a.stride_w;  // + r - pad is the input row
+        apix[i] = (unsigned)((img + (long long)h0 * a.sh + (long long)w0 * a.sw) * ES);
+        ahm[i] = range_mask(max(0, a.pad_h - h0), min(a.R - 1, a.Hi - 1 + a.pad_h - h0));
+        awm[i] = range_mask(max(0, a.pad_w - w0), min(a.S - 1, a.Wi - 1 + a.pad_w - w0));
       }
     } else {
-      abase[i] = 0;
-      ah0[i] = -(1 << 28);  // pushes every tap out of bounds
-      aw0[i] = -(1 << 28);
+      apix[i] = 0u;
+      ahm[i] = 0u;  // no tap is live
+      awm[i] = 0u;
     }
   }
-  long long bbase[B_IT];
-  bool bok[B_IT];
+  unsigned boff[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + trow + i * RPT;
-    bok[i] = n < a.Co;
-    bbase[i] = (long long)n * Ktot + kc * EPC;
+    const int nl = trow + i * RPT;
+    boff[i] = (n0 + nl < a.Co) ? (unsigned)(((long long)nl * Ktot + kcs * EPC) * ES) : OOB;
   }
 
   // taps visited: all of them, or (PAR) those with the parity of this class' pixels
@@ -204,37 +264,32 @@ igemm_kernel(ConvArgs a) {
   const int ns = s0 <= a.s_hi ? (a.s_hi - s0) / TSTEP + 1 : 0;
 
   u32x4 ra[A_IT], rb[B_IT];
-  int r = r0, s = s0, c0 = 0, kofs = (r0 * a.S + s0) * a.Ci;
+  unsigned avo[A_IT];  // per-lane offsets of the current tap (apix, or OOB where the tap is padding)
+  int r = r0, s = s0, c0 = 0;
+  int soA = 0, soB = 0;  // scalar byte offsets of the current K step (tap + channel slice), both operands
+  // The per-step bookkeeping below is a handful of scalar instructions; everything per-lane happens in
+  // set_tap(), once per tap.  (A wave issues one instruction every ~5 cycles whatever its kind, and what
+  // does not sit in the shadow of an MFMA adds to the step: a hundred "cheap" instructions per step
+  // cost as much as the step's sixteen MFMAs.)
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) avo[i] = (((ahm[i] >> r) & (awm[i] >> s)) & 1u) ? apix[i] : OOB;
+    // (readfirstlane: the values ARE wave-uniform, but once register pressure parks one of them in a VGPR
+    // the compiler wraps every load that uses it as a scalar offset in a serialising "waterfall" loop)
+    soA = __builtin_amdgcn_readfirstlane((int)((DGRAD ? (long long)(a.R - 1 - r) * shs + (long long)(a.S - 1 - s) * sws
+                                                      : (long long)r * a.sh + (long long)s * a.sw) * ES));
+    soB = __builtin_amdgcn_readfirstlane((r * a.S + s) * a.Ci * ES);
+    c0 = 0;
+  };
+  set_tap();
 
   auto gload = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int hi, wi;
-      bool ok;
-      if (DGRAD) {
-        const int hn = ah0[i] - r, wn_ = aw0[i] - s;
-        ok = ((hn & (a.stride_h - 1)) == 0) && ((wn_ & (a.stride_w - 1)) == 0);
-        hi = hn >> a.sh_log2;
-        wi = wn_ >> a.sw_log2;
-      } else {
-        hi = ah0[i] + r;
-        wi = aw0[i] + s;
-        ok = true;
-      }
-      ok = ok && ((unsigned)hi < (unsigned)a.Hi) && ((unsigned)wi < (unsigned)a.Wi);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const long long off = abase[i] + (long long)hi * a.sh + (long long)wi * a.sw + c0;
-        v = *reinterpret_cast<const u32x4*>(X + off);
-      }
-      ra[i] = v;
-    }
+    for (int i = 0; i < A_IT; ++i)
+      ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, avo[i], soA, 0));
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (bok[i]) v = *reinterpret_cast<const u32x4*>(Wt + bbase[i] + kofs);
-      rb[i] = v;
-    }
+    for (int i = 0; i < B_IT; ++i)
+      rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, boff[i], soB, 0));
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -248,14 +303,15 @@ igemm_kernel(ConvArgs a) {
       *reinterpret_cast<u32x4*>(ldsB + buf * BN * ROWB + row * ROWB + ((kc ^ swz<ROWB>(row)) << 4)) = rb[i];
     }
   };
+  // next K step: the next channel slice of this tap, or the first slice of the next tap
   auto advance = [&]() {
-    kofs += BK;
     c0 += BK;
+    soA += BK * ES;
+    soB += BK * ES;
     if (c0 >= a.Ci) {
-      c0 = 0;
       s += TSTEP;
       if (s > a.s_hi) { s = s0; r += TSTEP; }
-      kofs = (r * a.S + s) * a.Ci;
+      set_tap();
     }
   };
 
@@ -321,24 +377,14 @@ igemm_kernel(ConvArgs a) {
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int nk = nr * ns * (a.Ci / BK);  // 0 for a parity class no tap reaches (e.g. 1x1 stride 2)
-  if (nk > 0) {
-    gload();
-    lstore(0);
-  }
-  __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      advance();
-      gload();
-    }
-    const unsigned char* A_ = ldsA + (kt & 1) * BM * ROWB;
-    const unsigned char* B_ = ldsB + (kt & 1) * BN * ROWB;
+  // MFMAs of one K step on the tiles at A_ / B_
+  // (16-bit types: the 16-deep MFMA groups kk0 .. kk1-1 of the step; the DMA ring runs a step in two halves)
+  auto compute = [&](const unsigned char* A_, const unsigned char* B_, int kk0, int kk1) {
     if constexpr (sizeof(T) == 2) {
       typedef typename Mfma32<T>::frag frag;
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
+      for (int kk = kk0; kk < kk1; ++kk) {
         frag fa[MI], fb[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -380,9 +426,147 @@ igemm_kernel(ConvArgs a) {
           }
       }
     }
-    if (more) lstore((kt + 1) & 1);
+  };
+
+  if constexpr (!DMA) {
+    if (nk > 0) {
+      gload();
+      lstore(0);
+    }
     __syncthreads();
+    PDA_STAMP(2);  // first tile staged
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = kt + 1 < nk;
+      if (more) {
+        advance();
+        if (!PDA_ABL(1)) gload();
+      }
+      if (!PDA_ABL(2)) compute(ldsA + (kt & 1) * BM * ROWB, ldsB + (kt & 1) * BN * ROWB, 0, BK / 16);
+      if (more) lstore((kt + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // (device pass only: hipcc's host pass silently drops a kernel template whose body uses the LDS-DMA
+    // builtin and leaves its launch stub undefined; the host needs the stub, not the body)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One wave instruction moves 64 chunks = 1 KiB: the wave's (64 / CPR) rows of one pass, contiguous in LDS.
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef typename Mfma32<T>::frag frag;
+    constexpr int PIECES = A_IT + B_IT;  // DMA instructions per thread and tile
+    constexpr int KK = BK / 16, KH = KK / 2;
+    static_assert(KK == 2 || KK == 4, "a step is two halves of one or two 16-deep MFMA groups");
+    const int wave_off = __builtin_amdgcn_readfirstlane(wid) * 1024;
+    // fragment addresses of this lane inside one ring buffer, every (row group, kk) once for the whole kernel:
+    // the chunk swizzle is an XOR, so it cannot ride in the instruction's immediate offset - the ring stage can
+    unsigned offA[MI][KK], offB[NI][KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WTM + i * 32 + l31;
+        offA[i][kk] = row * ROWB + (((kk * 2 + lh) ^ swz<ROWB>(row)) << 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WTN + j * 32 + l31;
+        offB[j][kk] = NST * BM * ROWB + row * ROWB + (((kk * 2 + lh) ^ swz<ROWB>(row)) << 4);
+      }
+    }
+    // Ring discipline: tile kt lives in buffer kt % STAGES; see step() below for the order of one step.
+    // DMA data becomes visible to other waves' ds_reads only through the issuing waves' counted vmcnt wait
+    // followed by a barrier; the barrier is the raw instruction (a __syncthreads() would drain the DMAs that
+    // are meant to stay in flight).
+    // (The ring stage stays a run-time scalar: one arm per stage with the stage as a constant makes the compiler
+    // rotate the accumulators through a second register set - 128 more registers on the 256x256 tile, spills.)
+    int issued = 0;
+    auto issue = [&](int ST) {
+      unsigned char* da = ldsA + ST * BM * ROWB + wave_off;
+      unsigned char* db = ldsB + ST * BN * ROWB + wave_off;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_ptr)(da + i * RPT * ROWB), 16, avo[i], soA, 0, 0);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr)(db + i * RPT * ROWB), 16, boff[i], soB, 0, 0);
+    };
+    // Fragment reads run one 16-deep group AHEAD of the MFMAs, in a second register set: the reads of group
+    // g+1 are issued before the MFMAs of group g (a wave issues in order and an MFMA waits for the pipe, so
+    // reads placed after a group's MFMAs only start once the last of them has been issued, and their LDS
+    // latency then sits between the groups with nothing to hide it).  The last group of a step prefetches
+    // group 0 of the next tile, which the mid-step barrier has already made visible.
+    frag fa[2][MI], fb[2][NI];
+    auto fetch = [&](auto buf_, int ST, auto kk_) {
+      constexpr int B = decltype(buf_)::value, kk = decltype(kk_)::value;
+      const unsigned char* sa = lds + ST * BM * ROWB;
+      const unsigned char* sb = lds + ST * BN * ROWB;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[B][i] = *reinterpret_cast<const frag*>(sa + offA[i][kk]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[B][j] = *reinterpret_cast<const frag*>(sb + offB[j][kk]);
+    };
+    auto group = [&](auto kk_, int ST, int kt) {  // prefetch group kk+1 (or the next tile's group 0), MFMAs of group kk
+      constexpr int kk = decltype(kk_)::value, B = kk & 1;
+      if constexpr (kk + 1 < KK) {
+        fetch(std::integral_constant<int, B ^ 1>{}, ST, std::integral_constant<int, kk + 1>{});
+      } else {
+        if (kt + 1 < nk) fetch(std::integral_constant<int, B ^ 1>{}, ST + 1 == STAGES ? 0 : ST + 1, std::integral_constant<int, 0>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[B][i], fb[B][j], acc[i][j]);
+    };
+    static_assert(KK % 2 == 0, "the fragment double buffer alternates per group");
+    // One step = KK groups; the step's only barrier sits before the LAST group.  By then every read of tile
+    // kt has been issued (the last group's fragments were prefetched during the group before) and, after the
+    // lgkmcnt(0), has returned, so the barrier both publishes tile kt+1 (each wave waited for its own pieces)
+    // and frees tile kt's buffer, into which tile kt+STAGES is requested at once: STAGES-1 tiles are in flight
+    // while a step computes, with no more LDS than the ring itself.
+    auto wait_keep = [&](int younger) {  // wave-uniform: tiles younger than the awaited one that may stay in flight
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PIECES) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    auto step = [&](int ST, int kt) {
+      if (!PDA_ABL(2)) {
+        group(std::integral_constant<int, 0>{}, ST, kt);
+        if constexpr (KK == 4) {
+          group(std::integral_constant<int, 1>{}, ST, kt);
+          group(std::integral_constant<int, 2>{}, ST, kt);
+        }
+      }
+      if (kt + 1 < nk) {
+        wait_keep(issued - kt - 2);  // tile kt+1
+        __builtin_amdgcn_s_barrier();
+        if (issued < nk) {
+          advance();
+          if (!PDA_ABL(1)) issue(ST);
+          ++issued;
+        }
+      }
+      if (!PDA_ABL(2)) group(std::integral_constant<int, KK - 1>{}, ST, kt);
+    };
+    // prologue: the first STAGES tiles
+    for (; issued < STAGES && issued < nk; ++issued) {
+      if (issued > 0) advance();
+      issue(issued);
+    }
+    wait_keep(issued - 1);  // tile 0
+    __builtin_amdgcn_s_barrier();
+    PDA_STAMP(2);  // first tile staged
+    if (nk > 0) fetch(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      step(st, kt);
+      st = st + 1 == STAGES ? 0 : st + 1;
+    }
+#endif
+    __syncthreads();  // the epilogue restages the output tile through the ring's memory
   }
+
+  PDA_STAMP(3);  // main loop done
+  if (PDA_ABL(4)) return;  // diagnostics: no write-out
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (g&3)+8*(g>>2)+4*(lane>>5)
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
@@ -536,6 +720,7 @@ igemm_kernel(ConvArgs a) {
         a.psum[(long long)prow * a.Co + n0 + t] = v1;
         a.psq[(long long)prow * a.Co + n0 + t] = v2;
       }
+      PDA_STAMP(4);
       return;
     }
   } else if constexpr (!(EX && sizeof(T) == 2)) {
@@ -611,6 +796,8 @@ igemm_kernel(ConvArgs a) {
       }
     }
   }
+  PDA_STAMP(4);  // write-out done
+#undef PDA_STAMP
 }
 
 // ---------------------------------------------------------------- wgrad ----
@@ -949,28 +1136,47 @@ krsc_to_crsk_batched_kernel(const long long* __restrict__ meta, const int* __res
 }
 
 // ------------------------------------------------------------- host side ----
+// Diagnostics: with PDA_IGEMM_STAMPS=1 every igemm workgroup (block id < 8192) leaves 8 shader-clock stamps here.
+static unsigned long long* pda_conv_stamp_buffer() {
+  static unsigned long long* buf = [] {
+    const char* e = getenv("PDA_IGEMM_STAMPS");
+    unsigned long long* p = nullptr;
+    if (e && atoi(e) != 0 && hipMalloc(&p, 8192 * 8 * sizeof(unsigned long long)) != hipSuccess) p = nullptr;
+    return p;
+  }();
+  return buf;
+}
+PDA_EXPORT int pda_conv_stamps_read(unsigned long long* host_out) {  // [8192][8]; -1 when stamping is off
+  unsigned long long* b = pda_conv_stamp_buffer();
+  if (b == nullptr) return -1;
+  return (int)hipMemcpy(host_out, b, 8192 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+
 static int ilog2_exact(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
   return ((1 << l) == v) ? l : -1;
 }
 
-template <typename T, int BM, int BN, int ROWB>
+template <typename T, int BM, int BN, int ROWB, int WM = 2, int STAGES = 0>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
-  constexpr int NT = 256;
+  constexpr int NT = 128 * WM;
   const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
   if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
+#define PDA_IGEMM_LAUNCH(MODE_, EX_, GRID_)                                                                        \
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_, EX_, WM, STAGES>), dim3(GRID_), dim3(NT), 0, st, a)
   if (dgrad == MODE_DGRAD_S2) {
-    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, true>), dim3(4 * tiles), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD_S2, false>), dim3(4 * tiles), dim3(NT), 0, st, a);
+    if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, true, 4 * tiles);
+    else PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, false, 4 * tiles);
   } else if (dgrad == MODE_DGRAD) {
-    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD, true>), dim3(tiles), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_DGRAD, false>), dim3(tiles), dim3(NT), 0, st, a);
+    if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD, true, tiles);
+    else PDA_IGEMM_LAUNCH(MODE_DGRAD, false, tiles);
   } else {
-    if (ex) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, true>), dim3(tiles), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false>), dim3(tiles), dim3(NT), 0, st, a);
+    if (ex) PDA_IGEMM_LAUNCH(MODE_FPROP, true, tiles);
+    else PDA_IGEMM_LAUNCH(MODE_FPROP, false, tiles);
   }
+#undef PDA_IGEMM_LAUNCH
   return pda_check_launch();
 }
 
@@ -982,7 +1188,9 @@ static const long long kBigTiles = [] {
 }();
 
 // cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (each of the 2x2 waves owns
-// 128x64 outputs); bit 3 forces 64-byte K rows.
+// 128x64 outputs); bit 3 forces 64-byte K rows.  16-bit types only, LDS-DMA operand ring: 5 = 256x128 with
+// 4x2 waves and three 64-deep stages, 6 = 128x128 with 2x2 waves and four 32-deep stages, 7 = 256x256 with
+// 4x2 waves (64x128 outputs each) and four 32-deep stages.
 // big_ok: 16-bit plain kernel.  With the 128x128 tile every wave re-reads a 64-row A and a 64-row B slice
 // per 16 MFMAs and waits on those reads; a 128x64 wave tile moves 25 % fewer LDS bytes per MFMA and measured
 // 5-10 % faster in isolation on the deep layers at 28x28 and 14x14 - as long as there are enough tiles to fill the chip
@@ -1021,7 +1229,15 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   const bool shallow = ES == 2 && (cfg & 7) == 0 && !extras && (long long)a.R * a.S * a.Ci <= kShallowK;
   const int tile = pick_tile(a.M, a.Co, cfg, ES == 2 && !extras);
   const bool use128 = k128 && (cfg & 8) == 0 && !shallow && !((cfg & 7) == 0 && tile == 4);
-  if (tile == 4 && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
+  if ((tile == 4 || tile == 7) && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
+  if (tile >= 5) {
+    if constexpr (ES == 2) {
+      if (tile == 5 && k128) return launch_igemm<T, 256, 128, 128, 4, 3>(a, dgrad, st);
+      if (tile == 6) return launch_igemm<T, 128, 128, 64, 2, 4>(a, dgrad, st);
+      if (tile == 7) return launch_igemm<T, 256, 256, 64, 4, 4>(a, dgrad, st);
+    }
+    return -2;
+  }
   switch (tile) {
     case 1: return use128 ? launch_igemm<T, 128, 128, 128>(a, dgrad, st) : launch_igemm<T, 128, 128, 64>(a, dgrad, st);
     case 2: return use128 ? launch_igemm<T, 128, 64, 128>(a, dgrad, st) : launch_igemm<T, 128, 64, 64>(a, dgrad, st);
@@ -1034,7 +1250,7 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
 // Block-tile rows used for a given cfg/shape (python sizes the stats partials with it).
 PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg, int dtype, int extras) {
   const int tile = pick_tile(M, Co, cfg, dtype != PDA_F32 && !extras);
-  return tile == 3 ? 64 : tile == 4 ? 256 : 128;
+  return tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7) ? 256 : 128;
 }
 
 // Rows of per-tile sums a dgrad launch with bnc/psum writes: N x Hx x Wx x Cx is the dX tensor.
@@ -1042,7 +1258,7 @@ PDA_EXPORT int pda_conv_dgrad_stat_rows(int N, int Hx, int Wx, int Cx, int strid
   const bool par = stride_h == 2 && stride_w == 2 && (cfg & 16) == 0;
   const long long M = par ? (long long)N * ((Hx + 1) / 2) * ((Wx + 1) / 2) : (long long)N * Hx * Wx;
   const int tile = pick_tile((int)M, Cx, cfg);
-  const int bm = tile == 3 ? 64 : tile == 4 ? 256 : 128;
+  const int bm = tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7) ? 256 : 128;
   return (int)((M + bm - 1) / bm) * (par ? 4 : 1);
 }
 
@@ -1088,6 +1304,27 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
     a.Ha = (Ho + 1) / 2;
     a.Wb = (Wo + 1) / 2;
     a.M = N * a.Ha * a.Wb;
+  }
+  {
+    // the kernels address both operands with 32-bit byte offsets from a per-tile base (see igemm_kernel):
+    // everything one tile can reach must lie within 2 GiB of that base
+    if (R > 32 || S > 32) return -10;
+    if (dgrad && (sh % stride_h != 0 || sw % stride_w != 0)) return -10;
+    const long long es = dtype == PDA_F32 ? 4 : 2;
+    const long long row_hw = dgrad == MODE_DGRAD_S2 ? (long long)a.Ha * a.Wb : (long long)Ho * Wo;
+    const long long imgs = 255 / row_hw + 2;  // images a 256-row tile can touch
+    // rows / columns of the gathered tensor a tile can reach past its first image (Hi, Wi may be "unbounded"
+    // markers for pre-padded inputs, so bound them by what the output extent can touch)
+    const long long hs = dgrad ? (long long)Hi + R : std::min((long long)Hi, (long long)Ho * stride_h + R) + R + pad_h;
+    const long long ws = dgrad ? (long long)Wi + S : std::min((long long)Wi, (long long)Wo * stride_w + S) + S + pad_w;
+    const long long reach = (imgs * sn + hs * sh + ws * sw + Ci) * es;
+    if (reach >= 0x7fffffffLL || 256LL * R * S * Ci * es >= 0x7fffffffLL) return -10;
+    auto pattern = [](int st) { unsigned p = 0; for (int k = 0; k < 32; k += st) p |= 1u << k; return p; };
+    a.tap_pattern_h = pattern(stride_h);
+    a.tap_pattern_w = pattern(stride_w);
+    static const int kAblate = [] { const char* e = getenv("PDA_IGEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = kAblate;
+    a.stamps = pda_conv_stamp_buffer();
   }
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -5;
   if ((((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) != 0) return -5;

@@ -51,9 +51,10 @@ def param_generation() -> int:
 
 
 _TUNED: dict = {}
-# 0 = heuristic; 1/2/3 = 128x128, 128x64, 64x64 tiles; +8 = 32-deep K steps; 12 = 256x128 (128x64 per wave)
-_FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)
-_DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11)       # the fused-epilogue kernels have no 256x128 tile
+# 0 = heuristic; 1/2/3 = 128x128, 128x64, 64x64 tiles; +8 = 32-deep K steps; 12 = 256x128 (128x64 per wave);
+# 5/6/7 = LDS-DMA operand ring: 256x128 (8 waves, 3 x 64-deep), 128x128 (4 x 32-deep), 256x256 (8 waves, 4 x 32-deep)
+_FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
+_DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
 
 

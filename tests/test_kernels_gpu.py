@@ -70,7 +70,7 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
     assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], "wgrad"
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 10, 11, 12, 5, 6, 7])
 def test_conv_tile_configs(cfg):
     torch.manual_seed(2)
     N, H, W, Cin, K = 3, 10, 10, 128, 192
@@ -83,6 +83,49 @@ def test_conv_tile_configs(cfg):
     yf = y.float().view(-1, K)
     assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
     assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [5, 6, 7])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, R, stride, pad: ring shorter than / equal to / longer than its depth, ragged M and Co
+    (3, 10, 10, 128, 192, 3, 1, 1), (2, 14, 14, 128, 256, 1, 1, 0), (5, 9, 7, 64, 96, 1, 1, 0),
+    (2, 12, 12, 256, 128, 3, 2, 1), (2, 16, 16, 256, 64, 1, 2, 0), (40, 2, 2, 128, 128, 3, 1, 1)])
+def test_conv_lds_dma_ring_tiles(case, cfg, dtype):
+    """The LDS-DMA operand-ring tiles (buffer_load ... lds, source-side swizzle, counted vmcnt) against autograd:
+    fprop with statistics, fprop + residual + ReLU, dgrad (parity-split and every-tap) plain and with a residual."""
+    N, H, W, Cin, K, R, s, p = case
+    torch.manual_seed(5)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    w = (torch.randn(K, R, R, Cin, device=DEV) / (R * R * Cin) ** 0.5).to(dtype).permute(0, 3, 1, 2)
+    xr = x.float().requires_grad_(True)
+    yr = _ref_conv(xr, w.float(), s, p)
+    r = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), stats=True, cfg=cfg)
+    if r is None:
+        assert cfg & 7 == 5 and Cin % 64 != 0   # the 64-deep ring needs 128-byte K rows
+        return
+    y, psum, psq = r
+    assert rel_err(y, yr) < TOL[dtype], "fprop"
+    yf = y.float().view(-1, K)
+    assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
+    assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+    res = torch.randn_like(y)
+    if cfg & 7 != 7:   # the 256x256 tile has no fused-epilogue build
+        y2 = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), res=res, relu=True, cfg=cfg)
+        assert rel_err(y2, torch.relu(yr + res.float())) < TOL[dtype], "fprop+res+relu"
+    dy = torch.randn_like(yr).to(dtype)
+    yr.backward(dy.float())
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    rx = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    for extra in ((0, 16) if s == 2 else (0,)):
+        dx = C.dgrad_gpu(dy, wt, (H, W), (s, s), (p, p), cfg=cfg | extra)
+        if dx is None:
+            assert cfg & 7 == 5 and K % 64 != 0
+            continue
+        assert rel_err(dx, xr.grad) < TOL[dtype], ("dgrad", extra)
+        if cfg & 7 != 7:
+            dx = C.dgrad_gpu(dy, wt, (H, W), (s, s), (p, p), res=rx, cfg=cfg | extra)
+            assert rel_err(dx, xr.grad + rx.float()) < TOL[dtype], ("dgrad+res", extra)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])

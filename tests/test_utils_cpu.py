@@ -153,3 +153,24 @@ def test_seed_everything_reproducible():
     a = torch.rand(3)
     utils.seed_everything(7, warn=False)
     assert torch.equal(a, torch.rand(3))
+
+
+class _Marker:
+    """Any class of this module: a pickled instance needs a global lookup, which the safe loader refuses."""
+
+    def __init__(self):
+        self.touched = True
+
+
+def test_load_checkpoint_refuses_pickled_objects(tmp_path):
+    import pickle
+
+    from pytorch_distributed_amd.utils.checkpoint import load_checkpoint
+    ok = tmp_path / "ok.pth.tar"
+    torch.save({"epoch": 3, "arch": "resnet18", "state_dict": {"w": torch.ones(2)}, "best_acc1": 0.5}, ok)
+    assert load_checkpoint(str(ok))["epoch"] == 3
+    bad = tmp_path / "bad.pth.tar"
+    torch.save({"epoch": 3, "state_dict": {"w": torch.ones(2)}, "extra": _Marker()}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(str(bad))
+    assert load_checkpoint(str(bad), trusted=True)["extra"].touched   # explicit opt-in for files this job wrote
