@@ -571,6 +571,34 @@ PDA_EXPORT int pda_bn_eval_coeffs(int C, float eps, const float* gamma, const fl
   return pda_check_launch();
 }
 
+// Coefficient tables for a consumer that normalises its input on load (conv_igemm.hip, ConvArgs::in_scale):
+// lp[0][c], lp[1][c] = scale, shift rounded to the activation type; rt[0][c], rt[1][c] = those rounded values
+// back in fp32, which is what the backward's ReLU-mask recomputation must use so that it decides every element
+// the way the forward did.
+template <typename T>
+__global__ void bn_lp_tables_kernel(int C, const float* __restrict__ scale, const float* __restrict__ shift,
+                                    T* __restrict__ lp, float* __restrict__ rt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const T s = ElemTraits<T>::from_f32(scale[c]), f = ElemTraits<T>::from_f32(shift[c]);
+  lp[c] = s;
+  lp[C + c] = f;
+  rt[c] = ElemTraits<T>::to_f32(s);
+  rt[C + c] = ElemTraits<T>::to_f32(f);
+}
+
+PDA_EXPORT int pda_bn_lp_tables(int dtype, int C, const float* scale, const float* shift, void* lp, float* rt,
+                                hipStream_t st) {
+  if (C <= 0) return 0;
+  if (dtype == PDA_F16)
+    hipLaunchKernelGGL(bn_lp_tables_kernel<f16>, dim3((C + 127) / 128), dim3(128), 0, st, C, scale, shift, (f16*)lp, rt);
+  else if (dtype == PDA_BF16)
+    hipLaunchKernelGGL(bn_lp_tables_kernel<bf16>, dim3((C + 127) / 128), dim3(128), 0, st, C, scale, shift, (bf16*)lp, rt);
+  else
+    return -6;
+  return pda_check_launch();
+}
+
 // Grid for the register-resident-coefficient kernels: blocks*256 must be a multiple of
 // the vectors per row so a thread's channel vector never changes along its loop.
 static inline int ew_blocks_chan(long long nvec, int vpr) {

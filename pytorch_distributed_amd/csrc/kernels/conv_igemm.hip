@@ -54,6 +54,11 @@ struct ConvArgs {
   int r_lo, r_hi, s_lo, s_hi;  // taps that can touch a real pixel for at least one row (host-computed):
                                // on tiny feature maps (3x3 conv on a 1x1 or 2x2 map) most taps only see padding
   unsigned tap_pattern_h, tap_pattern_w;  // dgrad: bit k*stride set for every k (taps congruent to 0 mod stride)
+  // fprop of a consumer that normalises its own input (XF instantiations): the gathered tensor is the producer's
+  // conv output before its BatchNorm, and every loaded value becomes relu(v * in_scale[c] + in_shift[c]) on its
+  // way into LDS (tables of Ci values in the tensor's own 16-bit type); padding taps and rows past M stay zero
+  const void* in_scale;
+  const void* in_shift;
   unsigned long long* stamps;              // diagnostics (PDA_IGEMM_STAMPS=1): 8 s_memtime stamps per workgroup
   int ablate;                              // diagnostics (PDA_IGEMM_ABLATE), bits: 1 = no operand loads after the
                                            // prologue, 2 = no fragment reads / MFMAs, 4 = no epilogue (results are garbage either way)
@@ -81,6 +86,32 @@ template <> struct Mfma32<bf16> {
   }
 };
 
+// relu(v * sc + sf) on the eight 16-bit values of one 16-byte chunk (sc, sf: the chunk's eight channels).
+// fp16 runs as packed half-precision FMAs (one rounding, like the stand-alone pass that computes in fp32 and
+// rounds once; the tables themselves are rounded to fp16); bf16 has no packed FMA and goes through fp32.
+template <typename T> __device__ __forceinline__ u32x4 affine_relu8(u32x4 v, u32x4 sc, u32x4 sf);
+template <> __device__ __forceinline__ u32x4 affine_relu8<f16>(u32x4 v, u32x4 sc, u32x4 sf) {
+  // (as whole 8-element vectors: four v_pk_fma_f16 + four v_pk_max_f16)
+  const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const f16x8 r = __builtin_elementwise_fma(__builtin_bit_cast(f16x8, v), __builtin_bit_cast(f16x8, sc),
+                                            __builtin_bit_cast(f16x8, sf));
+  return __builtin_bit_cast(u32x4, __builtin_elementwise_max(r, zero));
+}
+template <> __device__ __forceinline__ u32x4 affine_relu8<bf16>(u32x4 v, u32x4 sc, u32x4 sf) {
+  u32x4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float lo = fmaxf(fmaf(__uint_as_float(v[d] << 16), __uint_as_float(sc[d] << 16), __uint_as_float(sf[d] << 16)), 0.f);
+    const float hi = fmaxf(fmaf(__uint_as_float(v[d] & 0xffff0000u), __uint_as_float(sc[d] & 0xffff0000u),
+                                __uint_as_float(sf[d] & 0xffff0000u)), 0.f);
+    const unsigned short l16 = __builtin_bit_cast(unsigned short, (bf16)lo);
+    const unsigned short h16 = __builtin_bit_cast(unsigned short, (bf16)hi);
+    o[d] = (unsigned)l16 | ((unsigned)h16 << 16);
+  }
+  return o;
+}
+template <> __device__ __forceinline__ u32x4 affine_relu8<float>(u32x4 v, u32x4, u32x4) { return v; }
+
 // rows per 256-byte LDS bank row and the chunk swizzle that spreads a 16-lane
 // ds_read_b128 group over all 64 banks.
 template <int ROWB> __device__ __forceinline__ int swz(int row) {
@@ -107,9 +138,12 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 // STAGES >= 3 (16-bit types): a ring of STAGES LDS buffers filled by LDS-DMA (buffer_load ... lds): the
 // operands never pass through registers, the tile of step t+2 is requested while step t computes, and the
 // only per-step synchronisation is one counted vmcnt + one barrier (see the main loop).
-template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0>
+// XF (fprop, 16-bit types, register-staged tiles): the input is normalised on load, see ConvArgs::in_scale.
+template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0, bool XF = false>
 __global__ void __launch_bounds__(128 * WM) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
+  static_assert(!XF || (MODE == MODE_FPROP && STAGES == 0 && sizeof(T) == 2 && !EX),
+                "input normalisation: plain forward kernels with register-staged operands");
   constexpr int NT = 128 * WM;             // threads per workgroup
   constexpr bool DMA = STAGES > 0;
   constexpr int NST = DMA ? STAGES : 2;    // LDS buffers per operand
@@ -283,6 +317,16 @@ igemm_kernel(ConvArgs a) {
   };
   set_tap();
 
+  // XF: scale / shift of this thread's eight channels of the current K step ride along with the tile loads
+  // (one 16-byte load each: the tables are tiny and stay in cache); `live` remembers which of the thread's
+  // rows were real pixels when the step was loaded, because the tap may have moved on by the time the
+  // registers are written to LDS
+  u32x4 xsc = {0u, 0u, 0u, 0u}, xsf = {0u, 0u, 0u, 0u};
+  unsigned xlive = 0u;
+  const auto rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_scale : nullptr), 0,
+                                                        XF ? a.Ci * ES : 0, 0x00020000);
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_shift : nullptr), 0,
+                                                        XF ? a.Ci * ES : 0, 0x00020000);
   auto gload = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
@@ -290,11 +334,23 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
       rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, boff[i], soB, 0));
+    if constexpr (XF) {
+      const int soC = __builtin_amdgcn_readfirstlane(c0 * ES);
+      xsc = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, kcs * 16, soC, 0));
+      xsf = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcF, kcs * 16, soC, 0));
+      xlive = 0u;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) xlive |= (avo[i] != OOB ? 1u : 0u) << i;
+    }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int row = trow + i * RPT;
+      if constexpr (XF) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        ra[i] = ((xlive >> i) & 1u) ? affine_relu8<T>(ra[i], xsc, xsf) : zero;
+      }
       *reinterpret_cast<u32x4*>(ldsA + buf * BM * ROWB + row * ROWB + ((kc ^ swz<ROWB>(row)) << 4)) = ra[i];
     }
 #pragma unroll
@@ -814,6 +870,8 @@ struct WgradArgs {
   float* slab;        // optional [nsplit][Co][Ktot] scratch: split-K partials stored, not atomically added
   long long slab_bytes;
   int r_lo, r_hi, s_lo, s_hi;  // taps outside this window only ever multiply padding: their dW stays zero
+  const void* in_scale;        // XF instantiations: x is normalised on load, relu(x * in_scale[c] + in_shift[c])
+  const void* in_shift;        // (Ci values of x's 16-bit type; padding stays zero), see ConvArgs::in_scale
   int det;                     // host side only: run-to-run reproducible split-K reduction (no float atomics
                                // racing on one element): slabs + ordered reduce, or a single split
 };
@@ -846,7 +904,7 @@ template <int PITCH> __device__ __forceinline__ int trswz(int px) {
   else return 0;
 }
 
-template <typename T, int TM, int TN, int BKP>
+template <typename T, int TM, int TN, int BKP, bool XF = false>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(WgradArgs a) {
   constexpr int EPC = 16 / sizeof(T);
@@ -893,6 +951,15 @@ wgrad_kernel(WgradArgs a) {
     xc = rem - xs * a.Ci;
   }
   const int hw = a.Ho * a.Wo;
+  // XF: the thread's chunk column is one tap and eight channels for the whole kernel, so their coefficients are
+  // loaded once
+  u32x4 xsc = {0u, 0u, 0u, 0u}, xsf = {0u, 0u, 0u, 0u};
+  if constexpr (XF) {
+    if (xok_c) {
+      xsc = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.in_scale) + xc);
+      xsf = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.in_shift) + xc);
+    }
+  }
 
   // (image, ho, wo) of every pixel row this thread gathers, kept up to date incrementally: a step
   // moves BKP pixels on, i.e. (dn, dh, dw) with one carry each - no integer division in the loop
@@ -910,7 +977,9 @@ wgrad_kernel(WgradArgs a) {
   }
 
   u32x4 ry[Y_IT], rx[X_IT];
+  unsigned xlive = 0u;  // XF: which of rx[] hold real pixels (the others stay exact zeros)
   auto gload = [&](int mstep) {
+    if constexpr (XF) xlive = 0u;
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
       const int px = ypx + i * RPY;
@@ -928,9 +997,11 @@ wgrad_kernel(WgradArgs a) {
       if (px < BKP && m < mend && xok_c) {
         const int hi = pho[i] * a.stride_h - a.pad_h + xr;
         const int wi = pwo[i] * a.stride_w - a.pad_w + xs;
-        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi)
+        if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
           v = *reinterpret_cast<const u32x4*>(X + (long long)pn[i] * a.sn + (long long)hi * a.sh +
                                               (long long)wi * a.sw + xc);
+          if constexpr (XF) xlive |= 1u << i;
+        }
       }
       rx[i] = v;
       // advance this row by BKP pixels for the next call (calls come in step order)
@@ -955,6 +1026,8 @@ wgrad_kernel(WgradArgs a) {
       const int px = xpx + i * RPX;
       if (px < BKP) {
         const int bo = (sizeof(T) == 2) ? ((xcc * 16) ^ trswz<PX>(px)) : xcc * 16;
+        // (transformed here, after the MFMAs of the running step, when the load has long arrived)
+        if constexpr (XF) { if ((xlive >> i) & 1u) rx[i] = affine_relu8<T>(rx[i], xsc, xsf); }
         *reinterpret_cast<u32x4*>(ldsX + buf * BKP * PX + px * PX + bo) = rx[i];
       }
     }
@@ -1164,6 +1237,16 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   constexpr int NT = 128 * WM;
   const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
   if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
+  if (a.in_scale != nullptr) {
+    // input normalised on load: plain forward launches of the register-staged 16-bit tiles only
+    if constexpr (sizeof(T) == 2 && STAGES == 0) {
+      if (dgrad != MODE_FPROP || ex || a.in_shift == nullptr) return -11;
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false, WM, 0, true>), dim3(tiles), dim3(NT), 0, st, a);
+      return pda_check_launch();
+    } else {
+      return -11;
+    }
+  }
 #define PDA_IGEMM_LAUNCH(MODE_, EX_, GRID_)                                                                        \
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_, EX_, WM, STAGES>), dim3(GRID_), dim3(NT), 0, st, a)
   if (dgrad == MODE_DGRAD_S2) {
@@ -1231,6 +1314,7 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   const bool use128 = k128 && (cfg & 8) == 0 && !shallow && !((cfg & 7) == 0 && tile == 4);
   if ((tile == 4 || tile == 7) && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
   if (tile >= 5) {
+    if (a.in_scale != nullptr) return -11;  // the LDS-DMA tiles move operands past the registers
     if constexpr (ES == 2) {
       if (tile == 5 && k128) return launch_igemm<T, 256, 128, 128, 4, 3>(a, dgrad, st);
       if (tile == 6) return launch_igemm<T, 128, 128, 64, 2, 4>(a, dgrad, st);
@@ -1264,13 +1348,15 @@ PDA_EXPORT int pda_conv_dgrad_stat_rows(int N, int Hx, int Wx, int Cx, int strid
 
 // Returns 0 on success, <0 if the shape is not covered by the MFMA kernels
 // (caller falls back to the direct kernels), >0 = hipError_t.
-PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
-                              const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
-                              float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
-                              long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
-                              int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
-                              hipStream_t stream) {
+static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
+                           const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
+                           float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                           long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
+                           int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
+                           const void* in_scale, const void* in_shift, hipStream_t stream) {
   ConvArgs a;
+  a.in_scale = in_scale; a.in_shift = in_shift;
+  if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
   a.stat_slots = stat_slots;
   a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.bnc = bnc; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
   a.psum = psum; a.psq = psq;
@@ -1337,6 +1423,32 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
   }
 }
 
+PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
+                              const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
+                              float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                              long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
+                              hipStream_t stream) {
+  return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
+                         sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
+                         nullptr, stream);
+}
+
+// Forward conv whose input is normalised on load: x holds the producing layer's conv output before its
+// BatchNorm; in_scale / in_shift are that BatchNorm's per-channel coefficients as Ci values of x's type, and the
+// kernel multiplies relu(x * in_scale + in_shift) into the GEMM (exact zeros for padding).  16-bit types and the
+// register-staged tiles (cfg 0-3, 9-12) only: <0 otherwise.
+PDA_EXPORT int pda_conv_igemm_xf(int dtype, const void* x, const void* w, void* y, const void* in_scale,
+                                 const void* in_shift, float* psum, float* psq, int N, int Hi, int Wi, int Ci,
+                                 long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
+                                 int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int stat_slots,
+                                 hipStream_t stream) {
+  if (in_scale == nullptr || in_shift == nullptr || dtype == PDA_F32) return -11;
+  return conv_igemm_impl(dtype, 0, x, w, y, nullptr, nullptr, nullptr, nullptr, nullptr, psum, psq, N, Hi, Wi, Ci, sn,
+                         sh, sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, 0, cfg, stat_slots, in_scale,
+                         in_shift, stream);
+}
+
 template <typename T, int TM, int TN, int BKP>
 static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   const int tiles = ((a.Co + TM - 1) / TM) * ((a.Ktot + TN - 1) / TN);
@@ -1368,7 +1480,12 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
     nsplit = 1;
     a.pix_per_split = ((a.M + BKP - 1) / BKP) * BKP;
   }
-  hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+  if (a.in_scale != nullptr) {
+    if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP, true>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+    else return -11;
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+  }
   if (slabs) {
     const long long n4 = n / 4;
     long long blocks = (n4 + 255) / 256;
@@ -1379,11 +1496,14 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
 }
 
 // dw must be zero-initialised (or hold the gradient to accumulate into).
-PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int Hi, int Wi, int Ci,
-                              long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
-                              int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int nsplit,
-                              float* workspace, long long workspace_bytes, hipStream_t stream) {
+static int conv_wgrad_impl(int dtype, const void* dy, const void* x, float* dw, int N, int Hi, int Wi, int Ci,
+                           long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
+                           int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int nsplit,
+                           float* workspace, long long workspace_bytes, const void* in_scale, const void* in_shift,
+                           hipStream_t stream) {
   WgradArgs a;
+  a.in_scale = in_scale; a.in_shift = in_shift;
+  if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
   a.slab = workspace; a.slab_bytes = workspace_bytes;
   a.dy = dy; a.x = x; a.dw = dw; a.sn = sn; a.sh = sh; a.sw = sw;
   a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.R = R; a.S = S;
@@ -1454,6 +1574,25 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
     default: return -6;
   }
 #undef PDA_W16
+}
+
+PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int Hi, int Wi, int Ci,
+                              long long sn, long long sh, long long sw, int Ho, int Wo, int Co, int R, int S,
+                              int stride_h, int stride_w, int pad_h, int pad_w, int cfg, int nsplit,
+                              float* workspace, long long workspace_bytes, hipStream_t stream) {
+  return conv_wgrad_impl(dtype, dy, x, dw, N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h,
+                         pad_w, cfg, nsplit, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// Weight gradient against an input that is normalised on load (see pda_conv_igemm_xf): 16-bit types only.
+PDA_EXPORT int pda_conv_wgrad_xf(int dtype, const void* dy, const void* x, float* dw, const void* in_scale,
+                                 const void* in_shift, int N, int Hi, int Wi, int Ci, long long sn, long long sh,
+                                 long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h, int stride_w,
+                                 int pad_h, int pad_w, int cfg, int nsplit, float* workspace,
+                                 long long workspace_bytes, hipStream_t stream) {
+  if (in_scale == nullptr || in_shift == nullptr || dtype == PDA_F32) return -11;
+  return conv_wgrad_impl(dtype, dy, x, dw, N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h,
+                         pad_w, cfg, nsplit, workspace, workspace_bytes, in_scale, in_shift, stream);
 }
 
 PDA_EXPORT int pda_krsc_to_crsk_batched(int dt_in, int dt_out, const long long* meta, const int* blk, int nblocks,

@@ -43,6 +43,7 @@ def _init_fusion_state(block) -> None:
     block.premask_in = False     # see ResNet.fuse_relu_backward
     block.premasked_out = False
     block.fuse_inner = True      # backward hand-off between the convs inside the block
+    block.defer_inner = (False, False)   # per inner hand-off: consumer normalises on load (set by the block)
     block._link_in = None        # per-forward: set by ResNet.features for the first conv
     block._link_out = None       # per-forward: read (and cleared) by ResNet.features
 
@@ -51,7 +52,8 @@ def _links(block, n_inner: int):
     """Per-forward backward links of a block: (link from the previous block, inner links, link to the
     next block, whether the block's output gradient arrives masked)."""
     in_link, block._link_in = (block._link_in if block.premask_in else None), None
-    inner = tuple(BNBackwardLink() if block.fuse_inner else None for _ in range(n_inner))
+    # inner hand-offs also skip the producer's normalisation pass where the consuming conv can apply it on load
+    inner = tuple(BNBackwardLink(defer=block.defer_inner[i]) if block.fuse_inner else None for i in range(n_inner))
     pm = _premasked_out(block)
     block._link_out = BNBackwardLink() if pm else None
     return in_link, inner, block._link_out, pm
@@ -73,6 +75,7 @@ class BasicBlock(tnn.Module):
         self.downsample = downsample
         self.stride = stride
         _init_fusion_state(self)
+        self.defer_inner = (pnn.ConvBnAct.takes_fused_path(self.conv2, torch.float16),)
 
     def forward(self, x):
         # `identity` is an alias of x handed back by conv1's op, so the gradient of the skip branch
@@ -106,6 +109,8 @@ class Bottleneck(tnn.Module):
         self.downsample = downsample
         self.stride = stride
         _init_fusion_state(self)
+        self.defer_inner = (pnn.ConvBnAct.takes_fused_path(self.conv2, torch.float16),
+                            pnn.ConvBnAct.takes_fused_path(self.conv3, torch.float16))
 
     def forward(self, x):
         in_link, (l1, l2), lo, pm = _links(self, 2)

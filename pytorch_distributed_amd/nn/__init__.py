@@ -127,6 +127,14 @@ class ConvBnAct(tnn.Module):
     sub-modules keep owning their parameters (so names stay ``conv1.weight`` / ``bn1.weight``)."""
 
     @staticmethod
+    def takes_fused_path(conv: Conv2d, dtype: torch.dtype) -> bool:
+        """Whether :meth:`run` sends this conv to the fused op (so a producer may defer its normalisation to it)."""
+        pointwise = conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+        return (conv.bias is None and conv.groups == 1 and conv.out_channels % 8 == 0
+                and bool(_conv.igemm_tiles(conv.in_channels, dtype))
+                and (pointwise or bool(_conv.igemm_tiles(conv.out_channels, dtype))))
+
+    @staticmethod
     def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
             residual: Optional[torch.Tensor] = None, passthrough: bool = False, mask_dx: bool = False,
             dout_premasked: bool = False, in_link=None, out_link=None):
@@ -152,6 +160,9 @@ class ConvBnAct(tnn.Module):
             # unfused modules (a bias, groups, or a channel count the MFMA kernels do not tile): the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
             # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
             # gradient mask on x
+            if in_link is not None and in_link.deferred:
+                from ..ops.fused import materialize_deferred
+                x = materialize_deferred(x, in_link)
             if (mask_dx or (in_link is not None and in_link.relu)) and x.is_cuda:
                 from ..ops.fused import grad_mask
                 x = grad_mask(x)

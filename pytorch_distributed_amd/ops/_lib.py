@@ -32,6 +32,11 @@ _SIGS = {
     "pda_conv_dgrad_stat_rows": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
     "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pda_conv_igemm_xf": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
+                          c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pda_conv_wgrad_xf": [c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
+                          c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
+    "pda_bn_lp_tables": [c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
     "pda_krsc_to_crsk":[c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],

@@ -54,6 +54,7 @@ _TUNED: dict = {}
 # 0 = heuristic; 1/2/3 = 128x128, 128x64, 64x64 tiles; +8 = 32-deep K steps; 12 = 256x128 (128x64 per wave);
 # 5/6/7 = LDS-DMA operand ring: 256x128 (8 waves, 3 x 64-deep), 128x128 (4 x 32-deep), 256x256 (8 waves, 4 x 32-deep)
 _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
+_FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
 
@@ -106,9 +107,15 @@ def make_weight(k: int, c: int, r: int, s: int, device=None, dtype=torch.float32
 def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pad: Tuple[int, int],
               res: Optional[torch.Tensor] = None, relu: bool = False, stats: bool = False, cfg: int = 0,
               geom: Optional[tuple] = None, stats_buf: Optional[torch.Tensor] = None,
-              bias: Optional[torch.Tensor] = None):
+              bias: Optional[torch.Tensor] = None, in_affine: Optional[tuple] = None):
     """y = conv(x, w) [+ bias] [+ res] [relu]; optionally also per-tile column sums for BatchNorm.
     ``bias``: fp32 ``[K]``, added in the GEMM epilogue (BatchNorm folded into the weights for inference).
+
+    ``in_affine = (scale, shift)`` (``[Ci]`` tensors of ``x``'s 16-bit dtype): ``x`` is the producing layer's
+    conv output *before* its BatchNorm and the kernel convolves ``relu(x * scale + shift)`` instead, applied to
+    the operand tiles on their way into LDS (padding stays exactly zero) - the normalised activation is never
+    written to memory.  Not combined with ``res`` / ``relu`` / ``bias``; ``None`` is returned when no kernel
+    covers the request (fp32, odd channel counts).
 
     ``geom`` overrides the gather geometry ``(N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S)`` for inputs
     that are not plain NHWC (the padded 4-channel stem image).  ``stats_buf`` (fp32 ``[2, slots, K]``,
@@ -126,10 +133,19 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     else:
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
     M = N * Ho * Wo
+    if in_affine is not None:
+        if res is not None or relu or bias is not None or x.element_size() != 2:
+            return None
+        xs, xf = in_affine
+        if not (xs.dtype == xf.dtype == x.dtype and xs.numel() == xf.numel() == Ci and xs.is_contiguous()
+                and xf.is_contiguous()):
+            raise ValueError("fprop_gpu: in_affine must be two contiguous [Ci] tensors of the input's dtype")
     if cfg == 0 and backends.benchmark and geom is None:
-        cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats),
-                         _FPROP_CFGS if res is None else _DGRAD_EX_CFGS,
-                         lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias))
+        cands = _FPROP_XF_CFGS if in_affine is not None else (_FPROP_CFGS if res is None else _DGRAD_EX_CFGS)
+        cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats,
+                                   in_affine is not None), cands,
+                         lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias,
+                                             in_affine))
     cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
     y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
     psum = psq = None
@@ -145,9 +161,14 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
             psum, psq = part[0], part[1]
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K or not bias.is_contiguous()):
         raise ValueError("fprop_gpu: bias must be a contiguous fp32 [K] tensor")
-    rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0, 0, 0,
-                          _lib.ptr(bias), _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S,
-                          stride[0], stride[1], pad[0], pad[1], int(relu), cfg, slots, _lib.stream())
+    if in_affine is not None:
+        rc = l.pda_conv_igemm_xf(_lib.dt(x), x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), in_affine[0].data_ptr(),
+                                 in_affine[1].data_ptr(), _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw,
+                                 Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, slots, _lib.stream())
+    else:
+        rc = l.pda_conv_igemm(_lib.dt(x), 0, x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), _lib.ptr(res), 0, 0, 0,
+                              _lib.ptr(bias), _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R,
+                              S, stride[0], stride[1], pad[0], pad[1], int(relu), cfg, slots, _lib.stream())
     if rc < 0:
         return None  # shape not covered by the MFMA kernels
     _lib.check(rc, "pda_conv_igemm(fprop)")
@@ -234,8 +255,10 @@ def _wgrad_workspace(device) -> Optional[torch.Tensor]:
 
 
 def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cfg: int = 0, nsplit: int = 0,
-              geom: Optional[tuple] = None, out: Optional[torch.Tensor] = None, workspace: bool = True):
-    """fp32 dW in KRSC layout, shape [K,R,S,C] (accumulates into ``out`` when given)."""
+              geom: Optional[tuple] = None, out: Optional[torch.Tensor] = None, workspace: bool = True,
+              in_affine: Optional[tuple] = None):
+    """fp32 dW in KRSC layout, shape [K,R,S,C] (accumulates into ``out`` when given).
+    ``in_affine``: as in :func:`fprop_gpu` - the gradient is taken against ``relu(x * scale + shift)``."""
     l = _lib.lib()
     K = dy.shape[-1]
     if geom is None:
@@ -246,16 +269,25 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
     if cfg == 0 and nsplit == 0 and backends.benchmark and geom is None:
         cfg = _tuned_cfg("wgrad", (dy.dtype, N, Hi, Wi, Ci, Ho, Wo, K, R, S, tuple(stride), tuple(pad), workspace,
-                                   backends.deterministic), _WGRAD_CFGS,
-                         lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, None, None, workspace))
+                                   backends.deterministic, in_affine is not None), _WGRAD_CFGS,
+                         lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, None, None, workspace,
+                                             in_affine))
     cfg &= (1 << 30) - 1
     if backends.deterministic:
         cfg |= 32
     dw = out if out is not None else torch.zeros((K, R, S, Ci), device=dy.device, dtype=torch.float32)
     ws = _wgrad_workspace(dy.device) if workspace else None
-    rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
-                          Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit,
-                          _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
+    if in_affine is not None:
+        if x.element_size() != 2:
+            return None
+        rc = l.pda_conv_wgrad_xf(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), in_affine[0].data_ptr(),
+                                 in_affine[1].data_ptr(), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S, stride[0],
+                                 stride[1], pad[0], pad[1], cfg, nsplit, _lib.ptr(ws),
+                                 0 if ws is None else ws.numel() * 4, _lib.stream())
+    else:
+        rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
+                              Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit,
+                              _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_conv_wgrad")

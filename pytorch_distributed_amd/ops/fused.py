@@ -20,7 +20,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib, conv as C, norm as Nm, pool as P
+from . import _lib, conv as C, norm as Nm, pool as P, streams
 
 
 # Smallest GEMM depth (Cout*R*S of the consuming conv's dgrad) for which the dgrad epilogue also takes the
@@ -49,6 +49,10 @@ def _conv_folded_bn(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.
     return C.fprop_gpu(x, w_f, stride, pad, res=res, relu=relu, bias=b_f)
 
 
+# Normalise-on-load between a conv+BatchNorm+ReLU and its single consumer (see BNBackwardLink.defer).
+_DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "1"
+
+
 class BNBackwardLink:
     """Hand-off between a fused op (the producer) and the ONE fused op that consumes its output.
 
@@ -60,14 +64,23 @@ class BNBackwardLink:
     per-channel sums (``sum g``, ``sum g*y``) that the producer's BatchNorm backward would otherwise get
     from a separate pass over ``g`` and ``y``; it leaves them in ``sums`` for the producer's backward,
     which runs next.  ``sums is None`` there (consumer in a fallback path) just means the producer reduces
-    the - already masked - gradient itself."""
+    the - already masked - gradient itself.
 
-    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums")
+    With ``defer=True`` the pair also skips the producer's normalisation pass in the FORWARD direction: the
+    producer hands its raw conv output on (``deferred`` set, ``xaffine`` = scale / shift in the activation
+    dtype) and the consumer's forward and weight-gradient kernels apply ``relu(y * scale + shift)`` to their
+    operand tiles on load (``conv.fprop_gpu(in_affine=...)``), so the normalised activation is neither written
+    nor read back.  Only a producer with a ReLU, no residual and batch statistics defers, and only for 16-bit
+    activations; a consumer that cannot fuse materialises the activation itself (``materialize_deferred``)."""
 
-    def __init__(self):
-        self.y = self.scale = self.shift = self.sums = None
+    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine")
+
+    def __init__(self, defer: bool = False):
+        self.y = self.scale = self.shift = self.sums = self.xaffine = None
         self.relu = True
         self.remask = False
+        self.defer = defer
+        self.deferred = False
 
 
 class _ConvBnActFn(torch.autograd.Function):
@@ -84,7 +97,17 @@ class _ConvBnActFn(torch.autograd.Function):
         w_lp = cache.low_precision(weight, dtype)
         train_stats = st.training or st.running_mean is None
         sbuf = cache.stats_buffer(K, x.device) if train_stats else None
-        r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats, stats_buf=sbuf)
+        in_aff = None
+        if in_link is not None and in_link.deferred:
+            # x is the producer's raw conv output: normalise it inside this conv's operand loads
+            assert not passthrough, "a deferred activation has exactly one consumer"
+            in_aff = in_link.xaffine
+            r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats, stats_buf=sbuf, in_affine=in_aff)
+            if r is None:
+                x = Nm.apply(x, in_link.scale, in_link.shift, None, True)
+                in_aff = None
+        if in_aff is None:
+            r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats, stats_buf=sbuf)
         if r is None:
             raise RuntimeError(
                 f"conv_bn_act: shape not supported by the MFMA kernels (Cin={Cin}, dtype={dtype}); "
@@ -102,17 +125,31 @@ class _ConvBnActFn(torch.autograd.Function):
             if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
                 mean, invstd = Nm.eval_moments(st)   # frozen statistics, trainable affine
             count = float(y.numel() // K)
-        out = Nm.apply(y, scale, shift, residual, relu)
+        ctx.premasked = bool(dout_premasked and relu)
+        defer = (out_link is not None and out_link.defer and ctx.premasked and train_stats and residual is None
+                 and y.element_size() == 2 and _DEFER_APPLY)
+        if defer:
+            # the consumer normalises on load; autograd still sees this tensor as "the activation"
+            out = y
+            out_link.deferred = True
+            xs, xf, rs, rf = Nm.lp_tables(scale, shift, dtype)
+            out_link.xaffine = (xs, xf)
+            # the mask recomputation in the consumer's dgrad epilogue decides with the same rounded coefficients
+            # as its forward did (an fp32 product and a 16-bit FMA of the same operands have the same sign)
+            out_link.scale, out_link.shift = rs, rf
+        else:
+            out = Nm.apply(y, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
         ctx.beta = beta
         ctx.mask_dx = mask_dx
-        ctx.premasked = bool(dout_premasked and relu)
+        ctx.in_aff = in_aff
         ctx.in_link = in_link
         ctx.out_link = out_link if dout_premasked else None
         if ctx.out_link is not None:
             out_link.relu = relu
             out_link.remask = relu and residual is None
-            out_link.scale, out_link.shift = scale, shift
+            if not defer:
+                out_link.scale, out_link.shift = scale, shift
             out_link.y = y if train_stats else None
             out_link.sums = None
         mask_src = out if (relu and not ctx.premasked and (residual is not None or not train_stats)) else None
@@ -152,6 +189,21 @@ class _ConvBnActFn(torch.autograd.Function):
             if mean is not None:
                 dg, db = Nm.eval_affine_grads(g, y, mean, invstd)
         dx = dw = None
+        # the weight gradient goes to the side stream when it accumulates in place (nothing in this pass
+        # reads it): it is launched first, so it runs beside this layer's dgrad and the layers below
+        wgrad_done = False
+        if ctx.needs_input_grad[1]:
+            sink = C.grad_sink(weight)
+            side = streams.fork(dy.device) if sink is not None else None
+            if side is not None:
+                with torch.cuda.stream(side):
+                    dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink, in_affine=ctx.in_aff)
+                if dwk is None:
+                    raise RuntimeError("conv_bn_act: wgrad shape not supported")
+                streams.keep_alive(side, dy, x)
+                streams.mark(dy.device)
+                C.notify_grad_ready(weight)
+                wgrad_done = True
         if ctx.needs_input_grad[0]:
             if dalias is not None:
                 dalias = dalias.contiguous()
@@ -160,7 +212,7 @@ class _ConvBnActFn(torch.autograd.Function):
             mask_x = ctx.mask_dx or (link is not None and link.relu)
             bn_in = sc = sf = None
             if (link is not None and link.y is not None and link.y.shape == x.shape and link.y.dtype == dy.dtype
-                    and K * R * S >= _SUMS_MIN_K):
+                    and (K * R * S >= _SUMS_MIN_K or ctx.in_aff is not None)):
                 bn_in = link.y
                 if link.relu and link.remask:
                     sc, sf, mask_x = link.scale, link.shift, False
@@ -180,7 +232,9 @@ class _ConvBnActFn(torch.autograd.Function):
                                   stride, pad)
                 if dalias is not None:
                     dx = dx + dalias
-                if mask_x or sc is not None:
+                if ctx.in_aff is not None:   # x is the raw conv output: the mask is that of the normalised value
+                    dx = dx * ((x.float() * link.scale + link.shift) > 0).to(dx.dtype)
+                elif mask_x or sc is not None:
                     dx = dx * (x > 0).to(dx.dtype)
             elif bn_in is not None:
                 dx, link.sums = r
@@ -189,9 +243,9 @@ class _ConvBnActFn(torch.autograd.Function):
         elif dalias is not None:
             masked = ctx.mask_dx or (ctx.in_link is not None and ctx.in_link.relu)
             dx = dalias * (x > 0).to(dalias.dtype) if masked else dalias
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not wgrad_done:
             sink = C.grad_sink(weight)
-            dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink)
+            dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink, in_affine=ctx.in_aff)
             if dwk is None:
                 raise RuntimeError("conv_bn_act: wgrad shape not supported")
             if sink is not None:
@@ -239,6 +293,27 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: N
             return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
                               cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link)
+
+
+class _MaterializeFn(torch.autograd.Function):
+    """``relu(y * scale + shift)`` of a deferred activation as a tensor, for a consumer that cannot normalise
+    on load.  Towards autograd the producer's output already *is* the activation, so the gradient passes
+    through unchanged (the consumer masks it, as ``in_link`` demands)."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift):
+        return Nm.apply(y.contiguous(), scale, shift, None, True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def materialize_deferred(x: torch.Tensor, in_link) -> torch.Tensor:
+    """``x`` itself, or the normalised activation if ``in_link`` says the producer deferred it."""
+    if in_link is None or not in_link.deferred:
+        return x
+    return _MaterializeFn.apply(x, in_link.scale, in_link.shift)
 
 
 class _GradMaskFn(torch.autograd.Function):

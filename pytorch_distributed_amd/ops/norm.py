@@ -119,6 +119,22 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = Fa
     return out[0], out[1], out[2], out[3], count
 
 
+def lp_tables(scale: torch.Tensor, shift: torch.Tensor, dtype: torch.dtype):
+    """``(scale_lp, shift_lp, scale_rt, shift_rt)``: the coefficients rounded to the 16-bit activation type (what a
+    consumer that normalises on load multiplies with) and those rounded values back in fp32 (what the ReLU-mask
+    recomputation of the backward pass has to use to agree with that forward element by element)."""
+    l = _lib.lib()
+    C = scale.numel()
+    C8 = (C + 7) // 8 * 8    # every table starts 16-byte aligned
+    lp = torch.empty((2, C8), device=scale.device, dtype=dtype)
+    rt = torch.empty((2, C8), device=scale.device, dtype=torch.float32)
+    if C8 != C:
+        raise ValueError("lp_tables: channel count must be a multiple of 8")
+    _lib.check(l.pda_bn_lp_tables(_lib.dt(dtype), C, scale.data_ptr(), shift.data_ptr(), lp.data_ptr(), rt.data_ptr(),
+                                  _lib.stream()), "pda_bn_lp_tables")
+    return lp[0], lp[1], rt[0], rt[1]
+
+
 def eval_coeffs(gamma, beta, st: BNState):
     l = _lib.lib()
     C = st.running_mean.numel()

@@ -23,7 +23,7 @@ from typing import Dict, List, Optional
 import torch
 from torch.optim import Optimizer
 
-from ..ops import multi_tensor as mt
+from ..ops import multi_tensor as mt, streams
 from ..ops.conv import bump_param_generation
 
 
@@ -159,6 +159,7 @@ class FusedSGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        streams.join()   # weight gradients still in flight on the backward pass' side stream (no-op normally)
         scaler = self._amp_scaler
         dev_scale = noop = None
         if scaler is not None and scaler.enabled:

@@ -49,7 +49,7 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.autograd import Variable
 
-from ..ops import multi_tensor as mt
+from ..ops import multi_tensor as mt, streams as _streams
 from .reducer import BucketPlan
 
 _MiB = 1 << 20
@@ -340,6 +340,7 @@ class DistributedDataParallel(nn.Module):
         return bk.wire
 
     def _launch(self, bk: _Bucket) -> None:
+        _streams.join()   # the bucket's weight gradients may still be running on the backward side stream
         buf = bk.flat
         if self.wire_dtype is not None:
             wire = self._wire_of(bk)
@@ -353,6 +354,7 @@ class DistributedDataParallel(nn.Module):
     def _finalize_backward(self) -> None:
         self._callback_queued = False
         self._in_backward = False
+        _streams.join()
         if not self.require_backward_grad_sync or not self._active:
             return
         if self._plan.num_unready():

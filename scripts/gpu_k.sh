@@ -1,5 +1,7 @@
 #!/bin/bash
+# kernel tests selected with -k "<expr>" (second argument: test file, default tests/test_kernels_gpu.py)
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 300 python -u -m pytest tests/test_kernels_gpu.py -m gpu -x -q --tb=short --timeout 120 --timeout-method thread -k "$1" > gpurun_out/pytest_gpu_k.log 2>&1
-rc=$?; tail -n 25 gpurun_out/pytest_gpu_k.log | cut -c1-300; exit $rc
+timeout -k 10 900 python -u -m pytest ${2:-tests/test_kernels_gpu.py} -q --timeout 300 --timeout-method thread -k "$1" > gpurun_out/k_pytest.log 2>&1; rc=$?
+tail -${3:-40} gpurun_out/k_pytest.log
+exit $rc

@@ -543,9 +543,11 @@ def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw, batch):
 @pytest.mark.parametrize("arch,dtype,hw,batch", [("resnet18", torch.float32, 32, 8), ("resnet50", torch.float32, 64, 8),
                                                  ("resnet50", torch.float16, 64, 16),
                                                  ("resnet50", torch.bfloat16, 64, 16)])
-def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch):
+def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch, monkeypatch):
     """Block-output ReLU masks applied in the next block's dgrad epilogue == applied by the owning BatchNorm
-    backward: the same gradients, train and eval mode."""
+    backward: the same gradients, train and eval mode.  (Normalise-on-load, which rides on the same links, is
+    switched off here: it rounds the forward differently and has its own tests.)"""
+    monkeypatch.setattr(fused, "_DEFER_APPLY", False)
     torch.manual_seed(21)
     m = models.get_model(arch).to(DEV).set_compute_dtype(dtype)
     x = torch.randn(batch, 3, hw, hw, device=DEV)
@@ -1025,3 +1027,142 @@ def test_resnet50_bench_configuration_parity_224_b64():
         assert opt._amp_scaler_ref.skipped_steps() == 0
     finally:
         backends.benchmark = old
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 9, 10, 11, 12])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, R, stride, pad
+    (3, 10, 10, 128, 192, 3, 1, 1), (2, 14, 14, 128, 256, 1, 1, 0), (5, 9, 7, 64, 96, 1, 1, 0),
+    (2, 12, 12, 256, 128, 3, 2, 1), (40, 2, 2, 128, 128, 3, 1, 1)])
+def test_conv_input_normalised_on_load(case, cfg, dtype):
+    """fprop / wgrad with ``in_affine``: the kernels multiply relu(x * scale + shift) into the GEMM while loading
+    the raw tensor.  Reference: the same convolution in fp32 on the separately normalised (and rounded)
+    activation.  The shift is kept positive on purpose: padding must contribute exact zeros, not relu(shift)."""
+    N, H, W, Cin, K, R, s, p = case
+    torch.manual_seed(7)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    w = (torch.randn(K, R, R, Cin, device=DEV) / (R * R * Cin) ** 0.5).to(dtype).permute(0, 3, 1, 2)
+    scale = (torch.rand(Cin, device=DEV) + 0.5).to(dtype)
+    shift = (torch.rand(Cin, device=DEV) * 0.5 + 0.1).to(dtype)
+    act = torch.relu(x.float() * scale.float() + shift.float()).to(dtype)
+    yr = _ref_conv(act, w, s, p)
+    r = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), stats=True, cfg=cfg, in_affine=(scale, shift))
+    assert r is not None
+    y, psum, psq = r
+    assert rel_err(y, yr) < TOL[dtype], "fprop"
+    yf = y.float().view(-1, K)
+    assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3     # rows past M and padding add nothing to the statistics
+    assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+    dy = torch.randn_like(yr).to(dtype)
+    dw_ref = C.wgrad_gpu(dy, act, R, R, (s, s), (p, p))
+    for wcfg in (0, 1, 2, 3, 9, 10, 11, 12, 13):
+        dw = C.wgrad_gpu(dy, x, R, R, (s, s), (p, p), cfg=wcfg, in_affine=(scale, shift))
+        if dw is None:
+            assert C.wgrad_gpu(dy, act, R, R, (s, s), (p, p), cfg=wcfg) is None
+            continue
+        assert rel_err(dw, dw_ref) < TOL[dtype], ("wgrad", wcfg)
+    # not available: fp32, a residual in the same launch, the LDS-DMA tiles
+    assert C.fprop_gpu(x.float(), C.krsc(w).float(), (s, s), (p, p), in_affine=(scale.float(), shift.float())) is None
+    assert C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), cfg=6, in_affine=(scale, shift)) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["bottleneck", "bottleneck_s2", "basic"])
+def test_deferred_batchnorm_apply_block_matches_two_pass(kind, dtype, monkeypatch):
+    """One residual block, inner conv+BN+ReLU layers handing their raw conv output to the consuming conv
+    (normalise on load in its forward and weight-gradient kernels) vs the stand-alone normalisation pass:
+    same output, same input gradient, same parameter gradients, and the pass really is gone."""
+    from pytorch_distributed_amd.models.resnet import Bottleneck, BasicBlock
+    import torch.nn as tnn
+    torch.manual_seed(23)
+    if kind == "basic":
+        blk = BasicBlock(64, 64)
+    else:
+        s = 2 if kind.endswith("s2") else 1
+        ds = tnn.Sequential(pnn.Conv2d(256, 512, 1, s, 0, bias=False), pnn.BatchNorm2d(512)) if s == 2 else None
+        blk = Bottleneck(256, 128 if s == 2 else 64, s, ds)
+    blk = blk.to(DEV)
+    for p in blk.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.5, 1.5) if p is not None else None
+    cin = 64 if kind == "basic" else 256
+    x0 = torch.relu(torch.randn(8, 20, 20, cin, device=DEV)).to(dtype)
+    real_apply = Nm.apply
+    out = []
+    for defer in (True, False):
+        monkeypatch.setattr(fused, "_DEFER_APPLY", defer)
+        n = [0]
+
+        def counting(*a, **k):
+            n[0] += 1
+            return real_apply(*a, **k)
+        monkeypatch.setattr(Nm, "apply", counting)
+        blk.train()
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        g = torch.randn(y.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(5)).to(dtype)
+        y.backward(g)
+        monkeypatch.setattr(Nm, "apply", real_apply)
+        out.append((n[0], y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    assert out[1][0] - out[0][0] == sum(blk.defer_inner) >= 1, (out[0][0], out[1][0])
+    # The two forms round the normalised activation differently (16-bit coefficients and one FMA rounding vs fp32
+    # arithmetic rounded at the end), so a few activations per thousand that sit within rounding of zero land on
+    # the other side of the ReLU; each form masks its own gradient consistently, but such an element's gradient
+    # then differs by its full value.  Hence: direction and bulk of the tensors instead of the largest deviation.
+    tol = 3 * TOL[dtype]
+
+    def close(a, b, what):
+        assert _cos(a, b) > (0.999 if dtype == torch.float16 else 0.98), (what, _cos(a, b))
+        if a.numel() >= 4096:
+            far = ((a.float() - b.float()).abs() > tol * b.float().abs().max()).float().mean().item()
+            assert far < 5e-3, (what, far)
+    assert rel_err(out[0][1], out[1][1]) < tol, "block output"
+    close(out[0][2], out[1][2], "input gradient")
+    for k in out[0][3]:
+        close(out[0][3][k], out[1][3][k], k)
+
+
+@pytest.mark.parametrize("arch,dtype", [("resnet50", torch.float16), ("resnet18", torch.float16),
+                                        ("resnext50_32x4d", torch.float16)])
+def test_deferred_batchnorm_apply_whole_model(arch, dtype, monkeypatch):
+    """Whole networks with the inner normalisation passes deferred: the launch counts drop by one per deferred
+    layer, and against an fp32 run of the same model the gradients are as close as those of the two-pass form
+    (16-bit rounding noise through 50 layers at this tiny size dominates either way, so the two 16-bit runs
+    are compared with the fp32 one rather than with each other)."""
+    torch.manual_seed(23)
+    m = models.get_model(arch).to(DEV)
+    x = torch.randn(16, 3, 64, 64, device=DEV)
+    t = torch.randint(0, 1000, (16,), device=DEV)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    real_apply = Nm.apply
+
+    def run(cd, defer):
+        monkeypatch.setattr(fused, "_DEFER_APPLY", defer)
+        n = [0]
+
+        def counting(*a, **k):
+            n[0] += 1
+            return real_apply(*a, **k)
+        monkeypatch.setattr(Nm, "apply", counting)
+        m.set_compute_dtype(cd)
+        m.load_state_dict(sd)
+        m.train()
+        m.zero_grad(set_to_none=True)
+        loss = ops.cross_entropy(m(x), t)
+        (loss * 128.0).backward()
+        monkeypatch.setattr(Nm, "apply", real_apply)
+        return n[0], loss.item(), torch.cat([p.grad.float().flatten() for p in m.parameters()])
+
+    n32, l32, g32 = run(torch.float32, True)          # fp32 never defers
+    n1, l1, g1 = run(dtype, True)
+    n0, l0, g0 = run(dtype, False)
+    blocks = [b for l in (m.layer1, m.layer2, m.layer3, m.layer4) for b in l]
+    # a layer defers when its consumer is a fused conv AND the layer itself runs as the fused op (ResNeXt's grouped
+    # 3x3 does neither)
+    expect = sum(sum(b.defer_inner) for b in blocks) if "resnext" not in arch else 0
+    assert n0 == n32 and n0 - n1 == expect, (n32, n0, n1, expect)
+    assert abs(l1 - l32) < 3e-2 * l32 and abs(l0 - l32) < 3e-2 * l32
+    c1, c0 = _cos(g1, g32), _cos(g0, g32)
+    assert c1 > c0 - 0.05, (c1, c0)
