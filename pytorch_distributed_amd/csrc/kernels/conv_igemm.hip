@@ -139,14 +139,24 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 // operands never pass through registers, the tile of step t+2 is requested while step t computes, and the
 // only per-step synchronisation is one counted vmcnt + one barrier (see the main loop).
 // XF (fprop, 16-bit types, register-staged tiles): the input is normalised on load, see ConvArgs::in_scale.
-template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0, bool XF = false>
+// SL (stride-1 "same" convolutions, e.g. 3x3 pad 1; LDS-DMA ring for the weights): the A operand of ALL taps of
+// a channel slice comes from one LDS-resident slab of input pixels.  The tile's BM consecutive output pixels
+// and their halo are addressed in zero-padded image coordinates, q = n*Hp*Wp + (h+pad)*Wp + (w+pad), so the pixel
+// under tap (r, s) of output row m sits at slab slot q(m) - q_lo + (r-pad)*Wp + (s-pad): one slab load per slice
+// (borders arrive as hardware zero-fill) serves R*S K-steps, and the L2 -> LDS traffic of the A operand drops by
+// about that factor - the implicit-GEMM tiles above re-fetch every input pixel once per tap and run into the
+// L2 -> CU bandwidth long before the matrix pipe is busy.
+template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0, bool XF = false,
+          bool SL = false>
 __global__ void __launch_bounds__(128 * WM) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
-  static_assert(!XF || (MODE == MODE_FPROP && STAGES == 0 && sizeof(T) == 2 && !EX),
-                "input normalisation: plain forward kernels with register-staged operands");
+  static_assert(!XF || (MODE == MODE_FPROP && (STAGES == 0 || SL) && sizeof(T) == 2 && !EX),
+                "input normalisation: plain forward kernels with register-staged operands or the slab");
+  static_assert(!SL || (STAGES == 4 && MODE != MODE_DGRAD_S2 && ROWB == 64), "slab: stride 1, 32-deep slices, 4-deep weight ring");
   constexpr int NT = 128 * WM;             // threads per workgroup
   constexpr bool DMA = STAGES > 0;
   constexpr int NST = DMA ? STAGES : 2;    // LDS buffers per operand
+  constexpr int NSLOT = 512;               // SL: pixel slots per slab buffer (the last one is kept all-zero)
   static_assert(!DMA || (sizeof(T) == 2 && STAGES >= 3 && STAGES <= 4), "LDS-DMA ring: 16-bit operands, 3-4 buffers");
   constexpr bool DGRAD = MODE != MODE_FPROP;
   constexpr bool PAR = MODE == MODE_DGRAD_S2;
@@ -161,13 +171,13 @@ igemm_kernel(ConvArgs a) {
   static_assert(MI >= 1 && NI >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
 
   // operand tiles (two stages); the 16-bit epilogue re-uses the space to stage the output tile
-  constexpr int TILE_BYTES = NST * (BM + BN) * ROWB;
+  constexpr int TILE_BYTES = SL ? (2 * NSLOT + NST * BN) * ROWB : NST * (BM + BN) * ROWB;
   constexpr int EPI_BYTES = sizeof(T) == 2 ? BM * (BN * (int)sizeof(T) + 16) : 0;
   constexpr int GRED_BYTES = (EX && sizeof(T) == 2) ? 2 * EPC * (NT + 8) * 4 : 0;  // BatchNorm-backward sums
   constexpr int LDS_BYTES0 = TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES0 > GRED_BYTES ? LDS_BYTES0 : GRED_BYTES];
   unsigned char* ldsA = lds;
-  unsigned char* ldsB = lds + NST * BM * ROWB;
+  unsigned char* ldsB = lds + (SL ? 2 * NSLOT : NST * BM) * ROWB;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wid = t >> 6;
@@ -508,6 +518,179 @@ igemm_kernel(ConvArgs a) {
     // One wave instruction moves 64 chunks = 1 KiB: the wave's (64 / CPR) rows of one pass, contiguous in LDS.
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef typename Mfma32<T>::frag frag;
+    if constexpr (SL) {
+      // ---- slab main loop (see the SL note above the kernel) ----
+      constexpr int S_IT = NSLOT * CPR / NT;   // slab DMA instructions per thread and channel slice
+      constexpr int ZSLOT = NSLOT - 1;         // never filled with data: rows past M read their A operand here
+      constexpr int PB = B_IT;                 // vector-memory instructions per thread: one weight tile ...
+      constexpr int PS = S_IT + (XF ? 2 : 0);  // ... and one slab (XF: plus the slice's scale / shift vectors)
+      static_assert(S_IT >= 1 && (NSLOT * ROWB) % (NT * 16) == 0, "whole passes of the workgroup fill a slab");
+      const int wave_off = __builtin_amdgcn_readfirstlane(wid) * 1024;
+      const int Wp = a.Wi + 2 * a.pad_w, HWp = (a.Hi + 2 * a.pad_h) * Wp;
+      const int halo = a.pad_h * Wp + a.pad_w;
+      const int nimg = a.M / row_hw;
+      int q_lo;
+      {
+        int n, ho, wo;
+        decode(m0, n, ho, wo);
+        q_lo = __builtin_amdgcn_readfirstlane(n * HWp + (ho + a.pad_h) * Wp + (wo + a.pad_w) - halo);
+      }
+      const auto rsrcSl = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(X) + (long long)n_first * a.sn, 0, 0x7fffffff,
+                                                             0x00020000);
+      // slab slots this lane fills (the same ones for every slice): source pixel, or out of range for borders,
+      // pixels past the last image and the zero slot
+      unsigned soff[S_IT];
+      const int kcl = lane & (CPR - 1);
+      int lchunk = 0;   // logical chunk this lane fetches: the same for all of its pieces (a piece starts at a
+                        // multiple of 16 slots, a whole number of swizzle periods)
+#pragma unroll
+      for (int it = 0; it < S_IT; ++it) {
+        const int slot = (it * (NT / 64) + wid) * (1024 / ROWB) + lane / CPR;
+        lchunk = kcl ^ swz<ROWB>(slot);
+        const int q = q_lo + slot;
+        const int n = q / HWp;
+        const int rem = q - n * HWp;
+        const int hp = rem / Wp;
+        const int h = hp - a.pad_h, w = rem - hp * Wp - a.pad_w;
+        const bool ok = slot != ZSLOT && n < nimg && (unsigned)h < (unsigned)a.Hi && (unsigned)w < (unsigned)a.Wi;
+        soff[it] = ok ? (unsigned)(((long long)(n - n_first) * a.sn + (long long)h * a.sh + (long long)w * a.sw +
+                                    lchunk * EPC) * ES)
+                      : OOB;
+      }
+      // slab slot (before the tap offset) of each output row this lane feeds to the MFMAs; -1: row past M
+      int sb[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        int n, ho, wo;
+        sb[i] = decode(m0 + wm * WTM + i * 32 + l31, n, ho, wo) ? n * HWp + (ho + a.pad_h) * Wp + (wo + a.pad_w) - q_lo : -1;
+      }
+      auto a_addr = [&](int i, int toff, int buf) -> unsigned {  // byte address of the row's K-group 0 fragment
+        const int sl = sb[i] < 0 ? ZSLOT : sb[i] + toff;
+        return (unsigned)(buf * NSLOT * ROWB + sl * ROWB + ((lh ^ swz<ROWB>(sl)) << 4));
+      };
+      unsigned offB[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WTN + j * 32 + l31;
+        offB[j] = row * ROWB + ((lh ^ swz<ROWB>(row)) << 4);
+      }
+      const int ntap = a.R * a.S;
+      const int nslice = a.Ci / BK;
+      const int nks = ntap * nslice;
+      // weight tiles are requested in (slice, tap) order
+      int i_tp = 0, i_c0 = 0, issued = 0;
+      auto issue_b = [&](int ST) {
+        const int so = __builtin_amdgcn_readfirstlane((i_tp * a.Ci + i_c0) * ES);
+        unsigned char* db = ldsB + ST * BN * ROWB + wave_off;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_ptr)(db + i * RPT * ROWB), 16, boff[i], so, 0, 0);
+        if (++i_tp == ntap) { i_tp = 0; i_c0 += BK; }
+        ++issued;
+      };
+      u32x4 xsc = {0u, 0u, 0u, 0u}, xsf = {0u, 0u, 0u, 0u};
+      const auto rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_scale : nullptr), 0,
+                                                            XF ? a.Ci * ES : 0, 0x00020000);
+      const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_shift : nullptr), 0,
+                                                            XF ? a.Ci * ES : 0, 0x00020000);
+      auto issue_slab = [&](int sc) {
+        const int so = __builtin_amdgcn_readfirstlane(sc * BK * ES);
+        unsigned char* da = lds + (sc & 1) * NSLOT * ROWB + wave_off;
+#pragma unroll
+        for (int it = 0; it < S_IT; ++it)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcSl, (lds_ptr)(da + it * (NT / 64) * 1024), 16, soff[it], so, 0, 0);
+        if constexpr (XF) {
+          xsc = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, lchunk * 16, so, 0));
+          xsf = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcF, lchunk * 16, so, 0));
+        }
+      };
+      // XF: every lane normalises, in place, exactly the chunks its own DMA instructions brought in (so its own
+      // vmcnt wait is all the synchronisation the pass needs; the step's barrier then publishes the result);
+      // zero-filled chunks stay zero
+      auto xf_slab = [&](int sc) {
+        if constexpr (XF) {
+          unsigned char* da = lds + (sc & 1) * NSLOT * ROWB + wave_off + lane * 16;
+#pragma unroll
+          for (int it = 0; it < S_IT; ++it) {
+            if (soff[it] != OOB) {
+              u32x4* pch = reinterpret_cast<u32x4*>(da + it * (NT / 64) * 1024);
+              *pch = affine_relu8<T>(*pch, xsc, xsf);
+            }
+          }
+        }
+      };
+      frag fa[2][MI], fb[2][NI];
+      unsigned caddr[MI], naddr[MI];
+      auto fetch = [&](auto buf_, const unsigned* aaddr, unsigned axor, int ST, unsigned bxor) {
+        constexpr int B = decltype(buf_)::value;
+        const unsigned char* sbp = ldsB + ST * BN * ROWB;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[B][i] = *reinterpret_cast<const frag*>(lds + (aaddr[i] ^ axor));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb[B][j] = *reinterpret_cast<const frag*>(sbp + (offB[j] ^ bxor));
+      };
+      auto mfmas = [&](auto buf_) {
+        constexpr int B = decltype(buf_)::value;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[B][i], fb[B][j], acc[i][j]);
+      };
+      // tap offsets: fprop reads the pixel at +(r - pad), dgrad (the transposed conv) at +(pad - r)
+      auto tap_off = [&](int tr, int ts) -> int {
+        return DGRAD ? (a.pad_h - tr) * Wp + (a.pad_w - ts) : (tr - a.pad_h) * Wp + (ts - a.pad_w);
+      };
+      // prologue: slab 0 and the first weight tiles; everything lands before the first step
+      issue_slab(0);
+      for (int i = 0; i < STAGES && i < nks; ++i) issue_b(i);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      xf_slab(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      PDA_STAMP(2);
+      int tr = 0, ts = 0, cs = 0;   // tap and slice of the running step
+#pragma unroll
+      for (int i = 0; i < MI; ++i) caddr[i] = a_addr(i, tap_off(0, 0), 0);
+      if (nks > 0) fetch(std::integral_constant<int, 0>{}, caddr, 0u, 0, 0u);
+      int st = 0;
+      for (int kt = 0; kt < nks; ++kt) {
+        const int tp = tr * a.S + ts;
+        // the step after this one
+        int ntr = tr, nts = ts + 1, ncs = cs;
+        if (nts == a.S) { nts = 0; ++ntr; }
+        if (ntr == a.R) { ntr = 0; ++ncs; }
+        const int nst = st + 1 == STAGES ? 0 : st + 1;
+        const bool more = kt + 1 < nks;
+        const bool slab_next = tp == 0 && cs + 1 < nslice;   // this step requests the next slice's slab
+        // K group 0: read group 1's fragments, multiply group 0's
+        fetch(std::integral_constant<int, 1>{}, caddr, 32u, st, 32u);
+        if (!PDA_ABL(2)) mfmas(std::integral_constant<int, 0>{});
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) naddr[i] = a_addr(i, tap_off(ntr, nts), ncs & 1);
+          if (XF && tp == ntap - 2 && cs + 1 < nslice) xf_slab(cs + 1);   // landed: three younger tiles have been awaited since
+          // weight tile kt+1 (and with it everything older, the next slab included) has landed once at most the
+          // younger requests remain: two weight tiles, plus the slab while it is younger than tile kt+1
+          const int younger = issued - kt - 2;
+          if (younger >= 2) {
+            if (tp >= 1 && tp <= 3 && cs + 1 < nslice) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PB + PS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PB) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          if (issued < nks && !PDA_ABL(1)) issue_b(st);
+          if (slab_next && !PDA_ABL(1)) issue_slab(cs + 1);
+          // K group 1: read the next step's group 0, multiply group 1
+          fetch(std::integral_constant<int, 0>{}, naddr, 0u, nst, 0u);
+        }
+        if (!PDA_ABL(2)) mfmas(std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int i = 0; i < MI; ++i) caddr[i] = naddr[i];
+        tr = ntr; ts = nts; cs = ncs; st = nst;
+      }
+    } else {
     constexpr int PIECES = A_IT + B_IT;  // DMA instructions per thread and tile
     constexpr int KK = BK / 16, KH = KK / 2;
     static_assert(KK == 2 || KK == 4, "a step is two halves of one or two 16-deep MFMA groups");
@@ -617,6 +800,7 @@ igemm_kernel(ConvArgs a) {
       step(st, kt);
       st = st + 1 == STAGES ? 0 : st + 1;
     }
+    }  // !SL
 #endif
     __syncthreads();  // the epilogue restages the output tile through the ring's memory
   }
@@ -1231,7 +1415,7 @@ static int ilog2_exact(int v) {
   return ((1 << l) == v) ? l : -1;
 }
 
-template <typename T, int BM, int BN, int ROWB, int WM = 2, int STAGES = 0>
+template <typename T, int BM, int BN, int ROWB, int WM = 2, int STAGES = 0, bool SL = false>
 static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.Co + BN - 1) / BN);
   constexpr int NT = 128 * WM;
@@ -1239,19 +1423,23 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
   if (a.in_scale != nullptr) {
     // input normalised on load: plain forward launches of the register-staged 16-bit tiles only
-    if constexpr (sizeof(T) == 2 && STAGES == 0) {
+    if constexpr (sizeof(T) == 2 && (STAGES == 0 || SL)) {
       if (dgrad != MODE_FPROP || ex || a.in_shift == nullptr) return -11;
-      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false, WM, 0, true>), dim3(tiles), dim3(NT), 0, st, a);
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false, WM, STAGES, true, SL>), dim3(tiles), dim3(NT), 0, st, a);
       return pda_check_launch();
     } else {
       return -11;
     }
   }
 #define PDA_IGEMM_LAUNCH(MODE_, EX_, GRID_)                                                                        \
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_, EX_, WM, STAGES>), dim3(GRID_), dim3(NT), 0, st, a)
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_, EX_, WM, STAGES, false, SL>), dim3(GRID_), dim3(NT), 0, st, a)
   if (dgrad == MODE_DGRAD_S2) {
-    if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, true, 4 * tiles);
-    else PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, false, 4 * tiles);
+    if constexpr (SL) {
+      return -12;
+    } else {
+      if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, true, 4 * tiles);
+      else PDA_IGEMM_LAUNCH(MODE_DGRAD_S2, false, 4 * tiles);
+    }
   } else if (dgrad == MODE_DGRAD) {
     if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD, true, tiles);
     else PDA_IGEMM_LAUNCH(MODE_DGRAD, false, tiles);
@@ -1279,6 +1467,7 @@ static const long long kBigTiles = [] {
 // 5-10 % faster in isolation on the deep layers at 28x28 and 14x14 - as long as there are enough tiles to fill the chip
 // twice, and with 32-deep K steps (the 64-deep version needs 96 KB of LDS: one workgroup per CU).
 static int pick_tile(int M, int Co, int cfg, bool big_ok = false) {
+  if (cfg & 64) return 8;  // slab tile (256x128), see dispatch_igemm
   int tile = cfg & 7;
   if (tile == 0) {
     const long long t128 = (long long)((M + 127) / 128) * ((Co + 127) / 128);
@@ -1313,6 +1502,21 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   const int tile = pick_tile(a.M, a.Co, cfg, ES == 2 && !extras);
   const bool use128 = k128 && (cfg & 8) == 0 && !shallow && !((cfg & 7) == 0 && tile == 4);
   if ((tile == 4 || tile == 7) && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
+  if (tile == 8) {
+    // cfg bit 6: 256x128 slab tile (8 waves): odd square-ish filters with "same" padding at stride 1, 32-channel
+    // slices; the slots a tile of 256 consecutive output pixels can reach (its rows and images in zero-padded
+    // coordinates plus the halo on both sides) must fit one slab buffer, whose last slot stays zero
+    if constexpr (ES == 2) {
+      if (dgrad == MODE_DGRAD_S2 || a.stride_h != 1 || a.stride_w != 1 || a.Hi != a.Ho || a.Wi != a.Wo) return -12;
+      if (a.R != 2 * a.pad_h + 1 || a.S != 2 * a.pad_w + 1 || a.R * a.S < 5) return -12;
+      const long long Wp = a.Wi + 2 * a.pad_w, halo = (long long)a.pad_h * Wp + a.pad_w;
+      const long long rows_crossed = (255 + a.Wo - 1) / a.Wo, imgs_crossed = (255 + (long long)a.Ho * a.Wo - 1) / ((long long)a.Ho * a.Wo);
+      const long long span = 255 + rows_crossed * 2 * a.pad_w + imgs_crossed * 2 * a.pad_h * Wp + 2 * halo + 1;
+      if (span > 511) return -12;
+      return launch_igemm<T, 256, 128, 64, 4, 4, true>(a, dgrad, st);
+    }
+    return -12;
+  }
   if (tile >= 5) {
     if (a.in_scale != nullptr) return -11;  // the LDS-DMA tiles move operands past the registers
     if constexpr (ES == 2) {
@@ -1334,7 +1538,7 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
 // Block-tile rows used for a given cfg/shape (python sizes the stats partials with it).
 PDA_EXPORT int pda_conv_igemm_bm(int M, int Co, int cfg, int dtype, int extras) {
   const int tile = pick_tile(M, Co, cfg, dtype != PDA_F32 && !extras);
-  return tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7) ? 256 : 128;
+  return tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7 || tile == 8) ? 256 : 128;
 }
 
 // Rows of per-tile sums a dgrad launch with bnc/psum writes: N x Hx x Wx x Cx is the dX tensor.
@@ -1342,7 +1546,7 @@ PDA_EXPORT int pda_conv_dgrad_stat_rows(int N, int Hx, int Wx, int Cx, int strid
   const bool par = stride_h == 2 && stride_w == 2 && (cfg & 16) == 0;
   const long long M = par ? (long long)N * ((Hx + 1) / 2) * ((Wx + 1) / 2) : (long long)N * Hx * Wx;
   const int tile = pick_tile((int)M, Cx, cfg);
-  const int bm = tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7) ? 256 : 128;
+  const int bm = tile == 3 ? 64 : (tile == 4 || tile == 5 || tile == 7 || tile == 8) ? 256 : 128;
   return (int)((M + bm - 1) / bm) * (par ? 4 : 1);
 }
 

@@ -53,6 +53,10 @@ def param_generation() -> int:
 _TUNED: dict = {}
 # 0 = heuristic; 1/2/3 = 128x128, 128x64, 64x64 tiles; +8 = 32-deep K steps; 12 = 256x128 (128x64 per wave);
 # 5/6/7 = LDS-DMA operand ring: 256x128 (8 waves, 3 x 64-deep), 128x128 (4 x 32-deep), 256x256 (8 waves, 4 x 32-deep)
+# (64 = slab tile, 256x128 with 8 waves for stride-1 "same" filters such as 3x3 pad 1: all taps of a channel slice
+# read one LDS-resident slab of input pixels.  It cuts the L2 traffic of the A operand ~9x but measured 5-40 %
+# slower than the tiles below on every ResNet-50 3x3 layer - the step time is set by the per-step wait / barrier /
+# fragment-read latency, not by L2 bandwidth (profiles/igemm_stamps_r2.txt) - so the tuner does not try it.)
 _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile

@@ -1166,3 +1166,62 @@ def test_deferred_batchnorm_apply_whole_model(arch, dtype, monkeypatch):
     assert abs(l1 - l32) < 3e-2 * l32 and abs(l0 - l32) < 3e-2 * l32
     c1, c0 = _cos(g1, g32), _cos(g0, g32)
     assert c1 > c0 - 0.05, (c1, c0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, R: tiles that span several images, ragged M, a single slice, wide rows, 5x5
+    (3, 10, 10, 128, 192, 3), (9, 14, 14, 64, 128, 3), (40, 7, 7, 32, 128, 3), (2, 56, 56, 64, 64, 3),
+    (5, 9, 13, 96, 96, 3), (70, 2, 2, 64, 128, 3), (2, 20, 20, 64, 128, 5)])
+def test_conv_slab_tile(case, dtype):
+    """cfg 64: the A operand of all taps of a channel slice comes from one LDS slab in zero-padded pixel coordinates
+    (one slab DMA per slice, a weight-tile ring per tap).  fprop with statistics, with residual + ReLU, with the
+    input normalised in the slab, and the stride-1 dgrad plain / with residual / with the BatchNorm-backward
+    epilogue, against fp32 references."""
+    N, H, W, Cin, K, R = case
+    p = R // 2
+    torch.manual_seed(11)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    w = (torch.randn(K, R, R, Cin, device=DEV) / (R * R * Cin) ** 0.5).to(dtype).permute(0, 3, 1, 2)
+    xr = x.float().requires_grad_(True)
+    yr = _ref_conv(xr, w.float(), 1, p)
+    r = C.fprop_gpu(x, C.krsc(w), (1, 1), (p, p), stats=True, cfg=64)
+    if H * W < 16:
+        assert r is None    # 256 consecutive pixels of tiny maps reach more padded slots than one slab holds
+        return
+    assert r is not None
+    y, psum, psq = r
+    assert rel_err(y, yr) < TOL[dtype], "fprop"
+    yf = y.float().view(-1, K)
+    assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
+    assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+    res = torch.randn_like(y)
+    y2 = C.fprop_gpu(x, C.krsc(w), (1, 1), (p, p), res=res, relu=True, cfg=64)
+    assert rel_err(y2, torch.relu(yr + res.float())) < TOL[dtype], "fprop+res+relu"
+    scale = (torch.rand(Cin, device=DEV) + 0.5).to(dtype)
+    shift = (torch.rand(Cin, device=DEV) * 0.5 + 0.1).to(dtype)
+    act = torch.relu(x.float() * scale.float() + shift.float()).to(dtype)
+    y3 = C.fprop_gpu(x, C.krsc(w), (1, 1), (p, p), cfg=64, in_affine=(scale, shift))
+    assert y3 is not None and rel_err(y3, _ref_conv(act, w, 1, p)) < TOL[dtype], "fprop normalised on load"
+    dy = torch.randn_like(yr).to(dtype)
+    yr.backward(dy.float())
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    dx = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (p, p), cfg=64)
+    assert dx is not None and rel_err(dx, xr.grad) < TOL[dtype], "dgrad"
+    rx = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    dx = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (p, p), res=rx, cfg=64)
+    assert rel_err(dx, xr.grad + rx.float()) < TOL[dtype], "dgrad+res"
+    # BatchNorm-backward epilogue: mask recomputed from the producer's tensor, per-channel sums of g and g*y
+    bn_in = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    sc = torch.rand(Cin, device=DEV) + 0.5
+    sf = torch.randn(Cin, device=DEV) * 0.3
+    r2 = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (p, p), cfg=64, bn_input=bn_in, bn_scale=sc, bn_shift=sf, bn_sums=True)
+    assert r2 is not None
+    g, sums = r2
+    gref = xr.grad * ((bn_in.float() * sc + sf) > 0)
+    assert rel_err(g, gref) < TOL[dtype], "dgrad+remask"
+    gf = g.float().view(-1, Cin)
+    assert rel_err(sums[0].sum(0), gf.sum(0)) < 5e-3
+    assert rel_err(sums[1].sum(0), (gf * bn_in.float().view(-1, Cin)).sum(0)) < 5e-3
+    # shapes the slab does not take
+    assert C.fprop_gpu(x, C.krsc(w), (2, 2), (p, p), cfg=64) is None
