@@ -246,7 +246,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                 const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
-                int relu) {
+                int relu, unsigned char* __restrict__ mask_out) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
@@ -268,6 +268,15 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
       o.v[e] = ElemTraits<T>::from_f32(f);
     }
     store16(out + i * EPC, o);
+    if (mask_out != nullptr) {
+      // one byte per 16-byte vector: bit e = element e is positive.  Whoever applies this layer's ReLU
+      // backward (the dgrad epilogue of the consuming conv) reads these bits instead of the activation:
+      // 1/16 of the bytes.
+      unsigned bits = 0u;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) bits |= (ElemTraits<T>::to_f32(o.v[e]) > 0.f ? 1u : 0u) << e;
+      mask_out[i] = (unsigned char)bits;
+    }
   }
 }
 
@@ -612,16 +621,29 @@ static inline int ew_blocks_chan(long long nvec, int vpr) {
   return (int)b;
 }
 
-PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out, const float* scale,
-                            const float* shift, long long M, int C, int relu, hipStream_t st) {
+static int bn_apply_impl(int dtype, const void* y, const void* res, void* out, const float* scale,
+                         const float* shift, long long M, int C, int relu, unsigned char* mask_out, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
   if (C % (16 / es) != 0) return -1;
   const long long nvec = M * C / (16 / es);
   if (nvec == 0) return 0;
   const int vpr = C / (16 / es);
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
-                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu));
+                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu, mask_out));
   return pda_check_launch();
+}
+
+PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out, const float* scale,
+                            const float* shift, long long M, int C, int relu, hipStream_t st) {
+  return bn_apply_impl(dtype, y, res, out, scale, shift, M, C, relu, nullptr, st);
+}
+
+// As pda_bn_apply, and mask_out[i] (one byte per 16-byte vector of `out`, M*C*sizeof(T)/16 bytes) gets the
+// "element is positive" bits of vector i.
+PDA_EXPORT int pda_bn_apply_mask(int dtype, const void* y, const void* res, void* out, const float* scale,
+                                 const float* shift, long long M, int C, int relu, unsigned char* mask_out,
+                                 hipStream_t st) {
+  return bn_apply_impl(dtype, y, res, out, scale, shift, M, C, relu, mask_out, st);
 }
 
 PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, const void* out, const float* mean,

@@ -29,7 +29,9 @@ struct ConvArgs {
   const void* w;    // [Co][R*S*Ci], K contiguous
   void* y;          // [M][Co]
   const void* res;  // optional [M][Co] added in the epilogue
-  const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res)
+  const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res);
+                    // with mask_bits: one byte per 16-byte vector of that tensor, bit e = element e is positive
+  int mask_bits;
   // BatchNorm backward of the layer that produced this conv's input, folded into a dgrad epilogue:
   // bnc = that layer's pre-normalisation tensor [M][Co].  With bn_scale/bn_shift the layer's ReLU mask
   // (bnc*scale+shift > 0) is applied to the output; with psum/psq the per-tile column sums of the final
@@ -850,8 +852,18 @@ igemm_kernel(ConvArgs a) {
       for (int k = 0; k < KE; ++k) rv[k] = load16(Rz + (eo[k] < 0 ? 0 : eo[k]));
     }
     if (Mk != nullptr) {
+      if (a.mask_bits) {
+        // the bits travel in the first element slot of the vector's registers
+        const unsigned char* __restrict__ Mb = reinterpret_cast<const unsigned char*>(a.mask);
 #pragma unroll
-      for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + (eo[k] < 0 ? 0 : eo[k]));
+        for (int k = 0; k < KE; ++k) {
+          const u32x4 b = {(unsigned)Mb[(eo[k] < 0 ? 0 : eo[k]) / EPC], 0u, 0u, 0u};
+          mv[k] = __builtin_bit_cast(Vec16<T>, b);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + (eo[k] < 0 ? 0 : eo[k]));
+      }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -919,9 +931,16 @@ igemm_kernel(ConvArgs a) {
             val.v[e] = ElemTraits<T>::from_f32(fmaxf(ElemTraits<T>::to_f32(val.v[e]), 0.f));
         }
         if (Mk != nullptr) {
+          if (a.mask_bits) {
+            const unsigned bits = __builtin_bit_cast(u32x4, mv[EX ? k : 0])[0];
 #pragma unroll
-          for (int e = 0; e < EPC; ++e)
-            if (!(ElemTraits<T>::to_f32(mv[EX ? k : 0].v[e]) > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+            for (int e = 0; e < EPC; ++e)
+              if (!((bits >> e) & 1u)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+              if (!(ElemTraits<T>::to_f32(mv[EX ? k : 0].v[e]) > 0.f)) val.v[e] = ElemTraits<T>::from_f32(0.f);
+          }
         }
         if (Bc != nullptr) {
 #pragma unroll
@@ -985,7 +1004,11 @@ igemm_kernel(ConvArgs a) {
           if (!DGRAD && a.bn_shift != nullptr && a.bnc == nullptr && ok) v += a.bn_shift[n];
           if (Rz != nullptr && ok) v += ElemTraits<T>::to_f32(Rz[o]);
           if (a.relu) v = fmaxf(v, 0.f);
-          if (Mk != nullptr && ok && !(ElemTraits<T>::to_f32(Mk[o]) > 0.f)) v = 0.f;
+          if (Mk != nullptr && ok) {
+            const bool pos = a.mask_bits ? ((reinterpret_cast<const unsigned char*>(a.mask)[o / EPC] >> (o % EPC)) & 1) != 0
+                                         : ElemTraits<T>::to_f32(Mk[o]) > 0.f;
+            if (!pos) v = 0.f;
+          }
           float cf = 0.f;
           if (Bc != nullptr && ok) {
             cf = ElemTraits<T>::to_f32(Bc[o]);
@@ -1557,9 +1580,10 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
                            float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
                            long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
                            int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
-                           const void* in_scale, const void* in_shift, hipStream_t stream) {
+                           const void* in_scale, const void* in_shift, hipStream_t stream, int mask_bits = 0) {
   ConvArgs a;
   a.in_scale = in_scale; a.in_shift = in_shift;
+  a.mask_bits = mask != nullptr ? mask_bits : 0;
   if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
   a.stat_slots = stat_slots;
   a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.bnc = bnc; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
@@ -1618,7 +1642,7 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
   }
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -5;
   if ((((uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) != 0) return -5;
-  if ((((uintptr_t)res | (uintptr_t)mask | (uintptr_t)bnc) & 15) != 0) return -5;
+  if ((((uintptr_t)res | (uintptr_t)bnc) & 15) != 0 || (!a.mask_bits && ((uintptr_t)mask & 15) != 0)) return -5;
   switch (dtype) {
     case PDA_F16: return dispatch_igemm<f16>(a, dgrad, cfg, stream);
     case PDA_BF16: return dispatch_igemm<bf16>(a, dgrad, cfg, stream);
@@ -1636,6 +1660,19 @@ PDA_EXPORT int pda_conv_igemm(int dtype, int dgrad, const void* x, const void* w
   return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
                          sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
                          nullptr, stream);
+}
+
+// pda_conv_igemm with `mask` given as sign bits (one byte per 16-byte vector of the [M][Co] tensor it stands for,
+// as written by pda_bn_apply_mask) instead of the tensor itself.
+PDA_EXPORT int pda_conv_igemm_maskbits(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
+                                       const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
+                                       float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                                       long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
+                                       int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
+                                       hipStream_t stream) {
+  return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
+                         sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
+                         nullptr, stream, 1);
 }
 
 // Forward conv whose input is normalised on load: x holds the producing layer's conv output before its

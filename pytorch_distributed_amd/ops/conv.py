@@ -182,12 +182,13 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
 def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], stride, pad,
               res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None,
               bn_input: Optional[torch.Tensor] = None, bn_scale: Optional[torch.Tensor] = None,
-              bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False):
+              bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False, mask_bits: bool = False):
     """dx[N,Hi,Wi,C] from dy[N,Ho,Wo,K]; w_crsk is the [C,R,S,K] transposed weight.
 
     ``res`` ([N,Hi,Wi,C]) is added in the epilogue; ``mask`` ([N,Hi,Wi,C], the forward input when that
     input was a ReLU output) zeroes dx wherever ``mask <= 0`` - the ReLU backward of the producer, applied
-    where the gradient is written instead of by a later pass over it.
+    where the gradient is written instead of by a later pass over it.  With ``mask_bits`` the mask is the
+    uint8 sign-bit tensor of that input (``norm.apply(want_mask=True)``: one byte per 16-byte vector).
 
     ``bn_input`` ([N,Hi,Wi,C]) is the pre-normalisation tensor of the BatchNorm that produced the forward
     input.  With ``bn_scale``/``bn_shift`` (fp32 [C]) that layer's ReLU mask ``bn_input*scale+shift > 0``
@@ -201,22 +202,26 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     if cfg == 0 and backends.benchmark:
         extras = res is not None or mask is not None or bn_input is not None
         cfg = _tuned_cfg("dgrad", (dy.dtype, N, Ho, Wo, K, C, R, S, Hi, Wi, tuple(stride), tuple(pad), res is not None,
-                                   mask is not None, bn_input is not None, bn_scale is not None, bn_sums),
+                                   mask is not None, bn_input is not None, bn_scale is not None, bn_sums, mask_bits),
                          _DGRAD_EX_CFGS if extras else _FPROP_CFGS,
                          lambda c: dgrad_gpu(dy, w_crsk, in_hw, stride, pad, res, c or 1 << 30, mask, bn_input, bn_scale,
-                                             bn_shift, bn_sums))
+                                             bn_shift, bn_sums, mask_bits))
     cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
-    for name, t in (("res", res), ("mask", mask), ("bn_input", bn_input)):
+    for name, t in (("res", res), ("mask", None if mask_bits else mask), ("bn_input", bn_input)):
         if t is not None and (t.shape != dx.shape or t.dtype != dx.dtype or not t.is_contiguous()):
             raise ValueError(f"dgrad_gpu: {name} must be a contiguous {tuple(dx.shape)} {dx.dtype} tensor")
+    if mask_bits and mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous()
+                                           or mask.numel() != dx.numel() * dx.element_size() // 16):
+        raise ValueError("dgrad_gpu: mask_bits wants one contiguous uint8 per 16 bytes of dx")
     sums = None
     if bn_sums:
         if bn_input is None:
             raise ValueError("dgrad_gpu: bn_sums needs bn_input")
         rows = l.pda_conv_dgrad_stat_rows(N, Hi, Wi, C, stride[0], stride[1], cfg)
         sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
-    rc = l.pda_conv_igemm(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
+    entry = l.pda_conv_igemm_maskbits if (mask_bits and mask is not None) else l.pda_conv_igemm
+    rc = entry(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
                           _lib.ptr(mask), _lib.ptr(bn_input), _lib.ptr(bn_scale), _lib.ptr(bn_shift),
                           sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
                           Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, 0,
@@ -231,7 +236,7 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
         if res is not None:
             dx += res
         if mask is not None:
-            dx *= (mask > 0).to(dx.dtype)
+            dx *= unpack_mask_bits(mask, dx) if mask_bits else (mask > 0).to(dx.dtype)
         if bn_input is not None and bn_scale is not None:
             dx *= ((bn_input.float() * bn_scale + bn_shift) > 0).to(dx.dtype)
         return (dx, None) if bn_sums else dx
@@ -239,6 +244,13 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
         return None
     _lib.check(rc, "pda_conv_igemm(dgrad)")
     return (dx, sums) if bn_sums else dx
+
+
+def unpack_mask_bits(bits: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """0/1 tensor shaped and typed like ``like`` from its sign-bit bytes (one byte per 16-byte vector)."""
+    epc = 16 // like.element_size()
+    sh = torch.arange(epc, device=bits.device, dtype=torch.uint8)
+    return ((bits.view(-1, 1) >> sh) & 1).reshape(like.shape).to(like.dtype)
 
 
 _WGRAD_WS: dict = {}

@@ -49,6 +49,9 @@ def _conv_folded_bn(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.
     return C.fprop_gpu(x, w_f, stride, pad, res=res, relu=relu, bias=b_f)
 
 
+# Block-output ReLU masks travel to the consuming conv's dgrad epilogue as sign bits (BNBackwardLink.maskbits).
+_MASK_BITS = os.environ.get("PDA_RELU_MASK_BITS", "1") == "1"
+
 # Normalise-on-load between a conv+BatchNorm+ReLU and its single consumer (see BNBackwardLink.defer).
 _DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "1"
 
@@ -70,13 +73,15 @@ class BNBackwardLink:
     producer hands its raw conv output on (``deferred`` set, ``xaffine`` = scale / shift in the activation
     dtype) and the consumer's forward and weight-gradient kernels apply ``relu(y * scale + shift)`` to their
     operand tiles on load (``conv.fprop_gpu(in_affine=...)``), so the normalised activation is neither written
-    nor read back.  Only a producer with a ReLU, no residual and batch statistics defers, and only for 16-bit
+    nor read back.  A producer whose ReLU follows a residual add (its mask cannot be recomputed from ``y``) leaves
+    the sign bits of its output in ``maskbits`` (one byte per 16-byte vector, written by the normalisation pass):
+    the consumer's epilogue reads those instead of the activation itself.  Only a producer with a ReLU, no residual and batch statistics defers, and only for 16-bit
     activations; a consumer that cannot fuse materialises the activation itself (``materialize_deferred``)."""
 
-    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine")
+    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine", "maskbits")
 
     def __init__(self, defer: bool = False):
-        self.y = self.scale = self.shift = self.sums = self.xaffine = None
+        self.y = self.scale = self.shift = self.sums = self.xaffine = self.maskbits = None
         self.relu = True
         self.remask = False
         self.defer = defer
@@ -137,6 +142,10 @@ class _ConvBnActFn(torch.autograd.Function):
             # the mask recomputation in the consumer's dgrad epilogue decides with the same rounded coefficients
             # as its forward did (an fp32 product and a 16-bit FMA of the same operands have the same sign)
             out_link.scale, out_link.shift = rs, rf
+        elif (out_link is not None and ctx.premasked and residual is not None and _MASK_BITS
+              and K % (16 // y.element_size()) == 0):
+            # the consumer masks this op's gradient: hand it the sign bits, 1/16 of the activation's bytes
+            out, out_link.maskbits = Nm.apply(y, scale, shift, residual, relu, want_mask=True)
         else:
             out = Nm.apply(y, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
@@ -216,9 +225,13 @@ class _ConvBnActFn(torch.autograd.Function):
                 bn_in = link.y
                 if link.relu and link.remask:
                     sc, sf, mask_x = link.scale, link.shift, False
+            mk, mkbits = (x if mask_x else None), False
+            if (mask_x and link is not None and link.maskbits is not None
+                    and link.maskbits.numel() * 16 == x.numel() * x.element_size()):
+                mk, mkbits = link.maskbits, True
             r = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
-                            res=dalias, mask=x if mask_x else None, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
-                            bn_sums=bn_in is not None)
+                            res=dalias, mask=mk, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                            bn_sums=bn_in is not None, mask_bits=mkbits)
             if r is None:
                 if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
                     # pointwise conv with a filter count the dgrad kernel does not step through (16, 24 in

@@ -158,11 +158,20 @@ def eval_affine_grads(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invs
     return (gf * ((y.float() - mean) * invstd)).sum(dims), gf.sum(dims)
 
 
-def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool, want_mask: bool = False):
+    """``relu(y * scale + shift + res)``.  ``want_mask``: also return the sign bits of the result, one byte per
+    16-byte vector (bit e = element e is positive): what the ReLU backward needs of this tensor, at 1/16 of its
+    size (``conv.dgrad_gpu(mask=..., mask_bits=True)``)."""
     l = _lib.lib()
     C = y.shape[-1]
     M = y.numel() // C
     out = torch.empty_like(y)
+    if want_mask:
+        bits = torch.empty(y.numel() * y.element_size() // 16, device=y.device, dtype=torch.uint8)
+        _lib.check(l.pda_bn_apply_mask(_lib.dt(y), y.data_ptr(), _lib.ptr(res), out.data_ptr(), scale.data_ptr(),
+                                       shift.data_ptr(), M, C, int(relu), bits.data_ptr(), _lib.stream()),
+                   "pda_bn_apply_mask")
+        return out, bits
     _lib.check(l.pda_bn_apply(_lib.dt(y), y.data_ptr(), _lib.ptr(res), out.data_ptr(), scale.data_ptr(),
                               shift.data_ptr(), M, C, int(relu), _lib.stream()), "pda_bn_apply")
     return out

@@ -1225,3 +1225,31 @@ def test_conv_slab_tile(case, dtype):
     assert rel_err(sums[1].sum(0), (gf * bn_in.float().view(-1, Cin)).sum(0)) < 5e-3
     # shapes the slab does not take
     assert C.fprop_gpu(x, C.krsc(w), (2, 2), (p, p), cfg=64) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("stride,cfg", [(1, 0), (2, 0), (1, 3), (2, 16), (1, 5)])
+def test_relu_mask_as_sign_bits(dtype, stride, cfg):
+    """The normalisation pass can leave the sign bits of its output (one byte per 16-byte vector); a dgrad epilogue
+    given those bits masks exactly like one given the activation tensor."""
+    torch.manual_seed(31)
+    N, H, W, Cin, K = 3, 12, 12, 64, 128
+    y = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    res = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    sc, sf = torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV) * 0.2
+    out_ref = Nm.apply(y, sc, sf, res, True)
+    out, bits = Nm.apply(y, sc, sf, res, True, want_mask=True)
+    assert torch.equal(out, out_ref)
+    assert bits.dtype == torch.uint8 and bits.numel() * 16 == out.numel() * out.element_size()
+    assert torch.equal(C.unpack_mask_bits(bits, out) > 0, out > 0)
+    if dtype == torch.float32 and cfg == 5:
+        return   # the LDS-DMA tiles are 16-bit only
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 24).to(dtype).permute(0, 3, 1, 2)
+    Ho = (H + 2 - 3) // stride + 1
+    dy = torch.randn(N, Ho, Ho, K, device=DEV).to(dtype)
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    rx = torch.randn_like(out)
+    a = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=rx, cfg=cfg, mask=out)
+    b = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=rx, cfg=cfg, mask=bits, mask_bits=True)
+    assert a is not None and b is not None and torch.equal(a, b)
+    assert (b[out <= 0] == 0).all()
