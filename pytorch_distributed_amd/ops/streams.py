@@ -84,6 +84,16 @@ def mark(device: torch.device) -> None:
             join()
 
 
+def pending(device: torch.device) -> Optional["torch.cuda.Stream"]:
+    """The side stream of ``device`` if work launched there has not been joined yet, else ``None``.  A consumer
+    that can run on the side stream itself (the gradient-bucket pack + all-reduce launch) orders itself after the
+    weight gradients that way without making the backward pass' stream wait for them."""
+    if device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _SIDE[idx] if _DIRTY.get(idx, False) else None
+
+
 def join() -> None:
     """The stream that forked (on every device with outstanding side work) waits for that work.  (Not "the
     current stream": the final callback of a backward pass runs after autograd has restored the thread's

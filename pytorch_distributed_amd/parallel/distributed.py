@@ -340,7 +340,20 @@ class DistributedDataParallel(nn.Module):
         return bk.wire
 
     def _launch(self, bk: _Bucket) -> None:
-        _streams.join()   # the bucket's weight gradients may still be running on the backward side stream
+        # The bucket's weight gradients may still be running on the backward pass' side stream.  The pack and the
+        # collective launch then go to that stream too (after whatever the main stream has written into the bucket
+        # so far): the all-reduce is ordered behind the gradients it sends while the input-gradient chain on the
+        # main stream keeps running.
+        side = _streams.pending(bk.flat.device) if self._on_device else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(bk.flat.device))
+            with torch.cuda.stream(side):
+                self._pack_and_reduce(bk)
+        else:
+            self._pack_and_reduce(bk)
+        bk.launched = True
+
+    def _pack_and_reduce(self, bk: _Bucket) -> None:
         buf = bk.flat
         if self.wire_dtype is not None:
             wire = self._wire_of(bk)
@@ -349,7 +362,6 @@ class DistributedDataParallel(nn.Module):
         elif self._pre != 1.0:
             buf.mul_(1.0 / self._pre)
         bk.work = self._coll.all_reduce(buf, "avg" if self._use_avg_op else "sum", async_op=True)
-        bk.launched = True
 
     def _finalize_backward(self) -> None:
         self._callback_queued = False
