@@ -256,9 +256,9 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e]; }
   for (; i < nvec; i += stride) {
-    Vec16<T> v = load16(y + i * EPC);
+    Vec16<T> v = load16_stream(y + i * EPC);
     Vec16<T> rv;
-    if (res) rv = load16(res + i * EPC);
+    if (res) rv = load16_stream(res + i * EPC);
     Vec16<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -267,7 +267,7 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
       if (relu) f = fmaxf(f, 0.f);
       o.v[e] = ElemTraits<T>::from_f32(f);
     }
-    store16(out + i * EPC, o);
+    store16_stream(out + i * EPC, o);
     if (mask_out != nullptr) {
       // one byte per 16-byte vector: bit e = element e is positive.  Whoever applies this layer's ReLU
       // backward (the dgrad epilogue of the consuming conv) reads these bits instead of the activation:
@@ -414,8 +414,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
     sf[e] = coef[4 * C + c0 + e];
   }
   for (; i < nvec; i += stride) {
-    Vec16<T> vd = load16(dout + i * EPC);
-    Vec16<T> vy = load16(y + i * EPC);
+    Vec16<T> vd = load16_stream(dout + i * EPC);
+    Vec16<T> vy = load16_stream(y + i * EPC);
     Vec16<T> vo;
     if (relu && out) vo = load16(out + i * EPC);
     Vec16<T> o, og;
@@ -430,8 +430,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
       o.v[e] = ElemTraits<T>::from_f32(cA[e] * gd + cB[e] * yv + cK[e]);
       og.v[e] = ElemTraits<T>::from_f32(gd);
     }
-    store16(dy + i * EPC, o);
-    if (dres) store16(dres + i * EPC, og);
+    store16_stream(dy + i * EPC, o);
+    if (dres) store16_stream(dres + i * EPC, og);
   }
 }
 

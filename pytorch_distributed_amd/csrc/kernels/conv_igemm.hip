@@ -340,6 +340,8 @@ igemm_kernel(ConvArgs a) {
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_shift : nullptr), 0,
                                                         XF ? a.Ci * ES : 0, 0x00020000);
   auto gload = [&]() {
+    // (default cache policy: marking the loads of a read-once 1x1 input non-temporal measured 0.6 % slower on the
+    // ResNet-50 step)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, avo[i], soA, 0));
@@ -414,7 +416,7 @@ igemm_kernel(ConvArgs a) {
       for (int k = 0; k < KI; ++k) {
         long long o;
         vec_offset(m0, k, o);  // a thread without a valid k-th vector reads element 0
-        bv[k] = load16(Bc0 + o);
+        bv[k] = load16_stream(Bc0 + o);
       }
     }
   }
@@ -849,7 +851,7 @@ igemm_kernel(ConvArgs a) {
     Vec16<T> rv[KE], mv[KE];
     if (Rz != nullptr) {
 #pragma unroll
-      for (int k = 0; k < KE; ++k) rv[k] = load16(Rz + (eo[k] < 0 ? 0 : eo[k]));
+      for (int k = 0; k < KE; ++k) rv[k] = load16_stream(Rz + (eo[k] < 0 ? 0 : eo[k]));
     }
     if (Mk != nullptr) {
       if (a.mask_bits) {
@@ -862,7 +864,7 @@ igemm_kernel(ConvArgs a) {
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < KE; ++k) mv[k] = load16(Mk + (eo[k] < 0 ? 0 : eo[k]));
+        for (int k = 0; k < KE; ++k) mv[k] = load16_stream(Mk + (eo[k] < 0 ? 0 : eo[k]));
       }
     }
 #pragma unroll
@@ -952,7 +954,7 @@ igemm_kernel(ConvArgs a) {
             g2[e] += vf * cf;
           }
         }
-        store16(Y + o, val);
+        store16_stream(Y + o, val);
       }
     }
     if (stats) __syncthreads();  // the statistics scratch below reuses the staging area

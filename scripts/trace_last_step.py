@@ -10,7 +10,8 @@ marker = sys.argv[2] if len(sys.argv) > 2 else "mt_sgd"
 f = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                 r.get("Queue_Id", "?") + "/" + r.get("Stream_Id", "?")))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
 # one step = from just after the optimizer launch of step n-2 to the optimizer launch of step n-1
@@ -18,12 +19,31 @@ ends = [marks[i] for i in range(len(marks)) if i + 1 == len(marks) or marks[i + 
 lo, hi = ends[-2] + 1, ends[-1] + 1
 step = rows[lo:hi]
 agg = collections.defaultdict(lambda: [0, 0])
-for s, e, n in step:
+per_queue = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in step:
     agg[n][0] += e - s
     agg[n][1] += 1
+    per_queue[q][0] += e - s
+    per_queue[q][1] += 1
+# time during which kernels of at least two different queues were running
+ev = sorted([(s, 1, q) for s, e, n, q in step] + [(e, -1, q) for s, e, n, q in step])
+live = collections.Counter()
+last_t, overlap, union = ev[0][0], 0, 0
+for t_, d, q in ev:
+    nq = sum(1 for v in live.values() if v > 0)
+    if nq >= 1:
+        union += t_ - last_t
+    if nq >= 2:
+        overlap += t_ - last_t
+    live[q] += d
+    last_t = t_
 busy = sum(v[0] for v in agg.values())
 wall = step[-1][1] - step[0][0]
-print(f"one step: {len(step)} launches, kernel time {busy / 1e6:.3f} ms, wall {wall / 1e6:.3f} ms")
+print(f"one step: {len(step)} launches, kernel time {busy / 1e6:.3f} ms, wall {wall / 1e6:.3f} ms, "
+      f"device busy {union / 1e6:.3f} ms, kernels of two queues running together {overlap / 1e6:.3f} ms")
+for q, (t_, c) in sorted(per_queue.items(), key=lambda kv: -kv[1][0]):
+    names = collections.Counter(n.split("(")[0][:40] for s_, e_, n, qq in step if qq == q).most_common(3)
+    print(f"  queue/stream {q}: {c} launches, {t_ / 1e6:.3f} ms  (mostly {', '.join(k for k, _ in names)})")
 groups = collections.defaultdict(float)
 for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f"{t / 1e6:8.3f} ms {c:5d}  {n[:140]}")
