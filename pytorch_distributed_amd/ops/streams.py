@@ -11,8 +11,8 @@ Protocol (all on one device, same stream priority as the compute stream: a wait 
 different priorities can starve the queue that is waited for):
 
 * ``fork()``: the side stream waits for everything the calling stream has been given so far
-  (the ``dy`` just produced); returns the side stream, or ``None`` when the feature is off, a hipGraph is
-  being captured, or the tensors are not on a GPU.
+  (the ``dy`` just produced); returns the side stream, or ``None`` when the feature is off or the tensors
+  are not on a GPU.
 * the caller launches on the side stream, calls ``keep_alive(...)`` for every tensor read there and
   ``mark()`` afterwards.
 * ``join()`` makes the calling stream wait for the side work launched so far.  It runs from an autograd
@@ -28,6 +28,8 @@ import torch
 from torch.autograd import Variable
 
 _ENABLED = os.environ.get("PDA_WGRAD_STREAM", "1") == "1"
+# Under hipGraph capture the fork / join events become graph edges, so the recorded step keeps the two branches.
+_IN_GRAPH = os.environ.get("PDA_WGRAD_STREAM_IN_GRAPH", "1") == "1"
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 _DIRTY: Dict[int, bool] = {}
 _ORIGIN: Dict[int, "torch.cuda.Stream"] = {}   # the stream the latest fork came from (the backward pass' stream)
@@ -46,7 +48,9 @@ def set_enabled(flag: bool) -> bool:
 
 
 def fork(device: torch.device) -> Optional["torch.cuda.Stream"]:
-    if not _ENABLED or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+    if not _ENABLED or device.type != "cuda":
+        return None
+    if not _IN_GRAPH and torch.cuda.is_current_stream_capturing():
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     side = _SIDE.get(idx)
