@@ -393,6 +393,8 @@ def worker(args) -> int:
         if not on_cpu:
             torch.cuda.synchronize()
 
+    host_dt = [0.0]
+
     def timed(step):
         with deadline.stage("warm-up", factor=2.0):
             loss = None
@@ -403,6 +405,7 @@ def worker(args) -> int:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 loss = step()
+            host_dt[0] = time.perf_counter() - t0     # launch-path time: the host is done issuing, the device is not
             fence()
             dt = time.perf_counter() - t0
         with deadline.stage("result reduce"):
@@ -428,6 +431,7 @@ def worker(args) -> int:
         comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
                                  "params": b["params"]} for b in model.bucket_summary()]
     ips = world * B * args.steps / dt
+    host_ms = 1000 * host_dt[0] / max(args.steps, 1)
     vs_stock = stock_ips = None
     if args.compare_stock and args.engine == "native" and not on_cpu:
         del model, step
@@ -457,6 +461,7 @@ def worker(args) -> int:
                        "weights": "random-init",
                        "conv_autotune": backends.benchmark if args.engine == "native" else None,
                        "final_loss": round(final_loss, 4), "hip_graph": graphed,
+                       "host_issue_ms_per_step": round(host_ms, 3),
                        "comm_backend": comm_info["comm_backend"], "rccl_nranks": comm_info["rccl_nranks"],
                        "wire_dtype": comm_info["wire_dtype"], "bucket_mb": comm_info["bucket_mb"],
                        "buckets": comm_info["buckets"],

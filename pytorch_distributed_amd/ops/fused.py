@@ -209,7 +209,7 @@ class _ConvBnActFn(torch.autograd.Function):
                     dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink, in_affine=ctx.in_aff)
                 if dwk is None:
                     raise RuntimeError("conv_bn_act: wgrad shape not supported")
-                streams.keep_alive(side, dy, x)
+                streams.keep_alive(side, dy, x, *(ctx.in_aff or ()))
                 streams.mark(dy.device)
                 C.notify_grad_ready(weight)
                 wgrad_done = True

@@ -174,3 +174,19 @@ def test_load_checkpoint_refuses_pickled_objects(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         load_checkpoint(str(bad))
     assert load_checkpoint(str(bad), trusted=True)["extra"].touched   # explicit opt-in for files this job wrote
+
+
+def test_wgrad_side_stream_is_inert_without_a_gpu():
+    """ops/streams.py: on CPU tensors (and with the switch off) fork() hands out no stream and join() is a no-op,
+    so the fused ops run their weight gradients in line."""
+    import torch
+    from pytorch_distributed_amd.ops import streams
+    assert streams.fork(torch.device("cpu")) is None
+    assert streams.pending(torch.device("cpu")) is None
+    old = streams.set_enabled(False)
+    try:
+        assert not streams.enabled()
+        assert streams.fork(torch.device("cpu")) is None
+    finally:
+        streams.set_enabled(old)
+    streams.join()   # nothing outstanding: must not touch any device
