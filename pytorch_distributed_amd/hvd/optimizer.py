@@ -48,6 +48,21 @@ class _Reducing:
         self._should_synchronize = True
         self._reduced_params = [p for p in params if p.requires_grad]
         self._hooks = [p.register_post_accumulate_grad_hook(self._hvd_hook) for p in self._reduced_params]
+        # This package's fused conv / BatchNorm ops accumulate weight gradients straight into an existing
+        # ``.grad`` (no AccumulateGrad node, so no autograd hook): they announce such a gradient through
+        # ``_pda_grad_ready`` instead, which keeps the reduction overlapped with the rest of backward.
+        for p in self._reduced_params:
+            if not hasattr(p, "_pda_grad_ready"):
+                p._pda_grad_ready = self._make_direct_ready(p)
+
+    def _make_direct_ready(self, p):
+        def ready():
+            if p.grad is None:
+                return
+            from ..ops import streams
+            streams.join()  # the gradient may have been launched on the backward side stream
+            self._hvd_hook(p)
+        return ready
 
     # -- gradient hooks -----------------------------------------------------------------------
     def _hvd_launch(self, p):

@@ -120,7 +120,7 @@ class FusedSGD(Optimizer):
                         p.grad.zero_()
             return
         params = [p for g in self.param_groups for p in g["params"]]
-        managed = any(hasattr(p, "_pda_grad_ready") for p in params)  # a DDP wrapper owns the gradient storage
+        managed = any(getattr(p, "_pda_ddp", None) is not None for p in params)  # a DDP wrapper owns the gradient storage
         if not managed and any(p.grad is not None and p.grad.is_cuda for p in params):
             self._build_arena()  # fresh zeros
             covered = {id(p) for p, _ in self._arena_ptrs}
