@@ -134,7 +134,16 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of the current HIP stream of the current device.  Called once per kernel launch (~2000 times per
+    ResNet-50 step): the two C entry points take ~0.3 us, ``torch.cuda.current_stream().cuda_stream`` builds a Python
+    Stream object first and took 9 us - a tenth of the step's host time."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
