@@ -235,6 +235,17 @@ def worker(args) -> int:
     if not on_cpu and not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible; bench.py needs an MI355X"}))
         return 2
+    # PDA_BENCH_SHARE_GPU=1: every rank uses GPU 0 - a rehearsal of the multi-rank path (supervisor, launcher,
+    # rendezvous, DDP buckets, side stream, fused wire) on a one-GPU box.  RCCL refuses two ranks on one device, so
+    # the collectives have to be the peer-memory ones (--comm p2p2); the JSON marks the run as not a result.
+    share_gpu = os.environ.get("PDA_BENCH_SHARE_GPU", "") == "1" and not on_cpu
+    if share_gpu:
+        local_rank = 0
+        if world > 1 and args.comm not in ("p2p2",):
+            if rank == 0:
+                print(json.dumps({"error": "PDA_BENCH_SHARE_GPU=1 needs --comm p2p2 (RCCL cannot put two ranks "
+                                           "on one device)"}), flush=True)
+            return 2
     if not on_cpu and torch.cuda.device_count() <= local_rank:
         print(json.dumps({"error": f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} "
                                    "GPU(s) visible"}), flush=True)
@@ -388,6 +399,11 @@ def worker(args) -> int:
         if world > 1:
             if comm_obj is not None and hasattr(comm_obj, "nranks"):
                 comm_obj.barrier(timeout_s=args.stage_timeout)    # device all-reduce on the data-plane communicator
+            elif not on_cpu and comm_kind != "torch":
+                # peer-memory data plane: drain the device, then meet on the gloo control plane (a default
+                # dist.barrier() would make torch build an RCCL communicator of its own)
+                torch.cuda.synchronize()
+                dist.all_reduce(torch.zeros(1))
             else:
                 dist.barrier()
         if not on_cpu:
@@ -457,7 +473,9 @@ def worker(args) -> int:
                        "amp_opt_level": args.opt_level if args.precision != "fp32" else "O0",
                        "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
-                       "device": "cpu (rehearsal, not a result)" if on_cpu else torch.cuda.get_device_name(dev),
+                       "device": ("cpu (rehearsal, not a result)" if on_cpu else
+                                  torch.cuda.get_device_name(dev) + (f" ({world} ranks sharing one GPU: rehearsal, "
+                                                                     "not a result)" if share_gpu and world > 1 else "")),
                        "weights": "random-init",
                        "conv_autotune": backends.benchmark if args.engine == "native" else None,
                        "final_loss": round(final_loss, 4), "hip_graph": graphed,

@@ -120,3 +120,23 @@ def test_hvd_optimizer_ranks_on_one_gpu(world):
     pack/cast/unpack groups (<= 3 launches each), a real all-gather, and device Adasum (halving / doubling with
     the HIP dot / combine kernels) against the fp64 host tree."""
     _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), world)
+
+
+def test_bench_supervisor_with_two_ranks_sharing_the_gpu():
+    """``python bench.py --gpus 2`` end to end on the one-GPU box: the supervisor starts two ranks through the
+    package's launcher, both use GPU 0 (PDA_BENCH_SHARE_GPU=1) and reduce their buckets through the peer-memory
+    two-shot kernel; the JSON line must describe a two-rank job and mark itself as a rehearsal."""
+    import json
+    env = dict(os.environ, PDA_BENCH_SHARE_GPU="1", PDA_BENCH_STAGE_TIMEOUT="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "p2p2",
+                        "--arch", "resnet18", "--batch-size", "32", "--image-size", "64", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 64
+    assert d["config"]["comm_backend"] == "p2p-twoshot" and d["config"]["wire_dtype"] == "float16"
+    assert "rehearsal" in d["config"]["device"] and d["value"] > 0
+    assert len(d["config"]["buckets"]) >= 1
