@@ -298,6 +298,8 @@ def worker(args) -> int:
         ok, why, c = 1, "", None
         with deadline.stage("RCCL communicator creation", factor=1.0):
             try:
+                if os.environ.get("PDA_BENCH_FAIL_NATIVE_COMM", "") == "1":   # test hook: exercise the fallback
+                    raise RuntimeError("native communicator disabled by PDA_BENCH_FAIL_NATIVE_COMM")
                 c = pcomm.device_communicator(dev)
                 if c is None:
                     raise RuntimeError("no communicator")

@@ -101,6 +101,9 @@ def slurm_world(gpus_per_task: int, local_gpu: int) -> RankInfo:
                     _slurm_master("127.0.0.1"), int(e.get("MASTER_PORT", "29500")), "slurm-spawn")
 
 
+_ADAPTER_CLONES: list = []
+
+
 class C10dStoreAdapter(dist.Store):
     """Expose a native store of this package through the c10d ``Store`` interface."""
 
@@ -140,6 +143,38 @@ class C10dStoreAdapter(dist.Store):
     @property
     def timeout(self):
         return self._timeout
+
+    # The rest of the c10d Store surface: ProcessGroupNCCL clones the store when it builds a communicator lazily
+    # (first collective on a device tensor), and newer torch releases probe the extended API.
+    def clone(self):
+        # the C++ side keeps only the C++ half of the returned object: the Python half (which carries these
+        # overrides) has to be kept alive here, or every later call lands on the pure-virtual base
+        c = C10dStoreAdapter(self._n)
+        c._timeout = self._timeout
+        _ADAPTER_CLONES.append(c)
+        return c
+
+    def has_extended_api(self):
+        return True
+
+    def append(self, key, value):
+        # (no atomic append in the native protocol: the c10d users of it - flight-recorder dumps, barrier lists -
+        # tolerate a read-modify-write between cooperating ranks that write distinct keys)
+        old = self._n.get(key, 0.0) if self._n.check([key]) else b""
+        self._n.set(key, bytes(old) + (value if isinstance(value, (bytes, bytearray)) else str(value).encode()))
+
+    def multi_get(self, keys):
+        return [self.get(k) for k in keys]
+
+    def multi_set(self, keys, values):
+        for k, v in zip(keys, values):
+            self.set(k, v)
+
+    def list_keys(self):
+        lk = getattr(self._n, "list_keys", None)
+        if lk is None:
+            raise NotImplementedError("list_keys is not part of the native store protocol")
+        return lk()
 
 
 def _make_store(init_method: str, rank: int, world_size: int, timeout_s: float):
@@ -206,6 +241,10 @@ def init_process_group(backend: Optional[str] = None, init_method: Optional[str]
         native = _make_store(init_method, info.rank, info.world_size, timeout.total_seconds())
         _STATE["store"] = native
         store = C10dStoreAdapter(PrefixStore("c10d", native))
+        # torch keeps only the C++ half of this object (inside its own PrefixStore); a communicator that is
+        # built lazily - at the first device collective, long after this function returned - still has to find
+        # the Python overrides
+        _ADAPTER_CLONES.append(store)
         if heartbeat:
             _STATE["heartbeat"] = Heartbeat(PrefixStore("pda", native), info.rank)
     if store is not None:
@@ -286,6 +325,7 @@ def destroy_process_group() -> None:
     _STATE["store"] = None
     if st is not None:
         st.close()
+    _ADAPTER_CLONES.clear()
 
 
 def enable_p2p_small_allreduce(max_elems: int = 65536, timeout_ms: int = 2000):

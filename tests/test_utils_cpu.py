@@ -190,3 +190,41 @@ def test_wgrad_side_stream_is_inert_without_a_gpu():
     finally:
         streams.set_enabled(old)
     streams.join()   # nothing outstanding: must not touch any device
+
+
+def test_c10d_store_adapter_outlives_init_process_group():
+    """torch keeps only the C++ half of the store object handed to init_process_group; a backend that is built lazily
+    (ProcessGroupNCCL at the first device collective) calls into it - and clones it - long after that function
+    returned.  The Python overrides must still be reachable then."""
+    import gc
+    import socket
+    import torch.distributed as dist
+    from pytorch_distributed_amd import comm as pcomm
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    old = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("RANK", None)
+    os.environ.pop("WORLD_SIZE", None)
+    try:
+        pcomm.init_process_group("gloo", rank=0, world_size=1)
+        gc.collect()
+        st = dist.distributed_c10d._get_default_store()     # torch's C++ PrefixStore around the adapter
+        st.set("late", b"value")
+        assert bytes(st.get("late")) == b"value" and st.check(["late"])
+        if hasattr(st, "clone"):
+            c = st.clone()
+            gc.collect()
+            assert bytes(c.get("late")) == b"value"
+            c.set("late2", b"x")
+            assert bytes(st.get("late2")) == b"x"
+        assert st.add("ctr", 2) == 2 and st.add("ctr", 3) == 5
+    finally:
+        pcomm.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
