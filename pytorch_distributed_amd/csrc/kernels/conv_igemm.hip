@@ -335,6 +335,7 @@ igemm_kernel(ConvArgs a) {
   // registers are written to LDS
   u32x4 xsc = {0u, 0u, 0u, 0u}, xsf = {0u, 0u, 0u, 0u};
   unsigned xlive = 0u;
+  const bool xsel = XF && (a.R * a.S > 1 || a.pad_h != 0 || a.pad_w != 0);
   const auto rsrcS = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_scale : nullptr), 0,
                                                         XF ? a.Ci * ES : 0, 0x00020000);
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(XF ? a.in_shift : nullptr), 0,
@@ -352,9 +353,11 @@ igemm_kernel(ConvArgs a) {
       const int soC = __builtin_amdgcn_readfirstlane(c0 * ES);
       xsc = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, kcs * 16, soC, 0));
       xsf = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcF, kcs * 16, soC, 0));
-      xlive = 0u;
+      if (xsel) {
+        xlive = 0u;
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) xlive |= (avo[i] != OOB ? 1u : 0u) << i;
+        for (int i = 0; i < A_IT; ++i) xlive |= (avo[i] != OOB ? 1u : 0u) << i;
+      }
     }
   };
   auto lstore = [&](int buf) {
@@ -362,8 +365,11 @@ igemm_kernel(ConvArgs a) {
     for (int i = 0; i < A_IT; ++i) {
       const int row = trow + i * RPT;
       if constexpr (XF) {
+        // pointwise convs have no padding taps: their only dead rows are those past M in the last tile, which
+        // the statistics below skip explicitly, so the select is only paid where padding exists
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        ra[i] = ((xlive >> i) & 1u) ? affine_relu8<T>(ra[i], xsc, xsf) : zero;
+        const u32x4 v = affine_relu8<T>(ra[i], xsc, xsf);
+        ra[i] = (xsel && !((xlive >> i) & 1u)) ? zero : v;
       }
       *reinterpret_cast<u32x4*>(ldsA + buf * BM * ROWB + row * ROWB + ((kc ^ swz<ROWB>(row)) << 4)) = ra[i];
     }
@@ -878,8 +884,8 @@ igemm_kernel(ConvArgs a) {
           const T tv = ElemTraits<T>::from_f32(acc[i][j][g]);
           *reinterpret_cast<T*>(lds + row * CP + col * (int)sizeof(T)) = tv;
           if (stats && !gstats) {
-            // rows past M come from all-zero A rows, so they add nothing
-            const float fv = ElemTraits<T>::to_f32(tv);
+            // rows past M come from all-zero A rows, so they add nothing (XF: a normalised zero is not zero)
+            const float fv = (!XF || m0e + row < a.M) ? ElemTraits<T>::to_f32(tv) : 0.f;
             csum[j] += fv;
             csq[j] += fv * fv;
           }

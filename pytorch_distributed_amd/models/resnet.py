@@ -15,6 +15,7 @@ or ``amp.initialize`` for mixed precision) with fp32 master parameters.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Type, Union
 
 import torch
@@ -23,6 +24,10 @@ import torch.nn as tnn
 from .. import nn as pnn
 from .. import ops
 from ..ops.fused import BNBackwardLink
+
+
+# diagnostics: bit i = the i-th inner hand-off of a block may skip its normalisation pass (3 = both)
+_DEFER_MASK = int(os.environ.get("PDA_DEFER_INNER_MASK", "3"))
 
 
 def _conv3x3(cin, cout, stride=1, groups=1):
@@ -53,7 +58,8 @@ def _links(block, n_inner: int):
     next block, whether the block's output gradient arrives masked)."""
     in_link, block._link_in = (block._link_in if block.premask_in else None), None
     # inner hand-offs also skip the producer's normalisation pass where the consuming conv can apply it on load
-    inner = tuple(BNBackwardLink(defer=block.defer_inner[i]) if block.fuse_inner else None for i in range(n_inner))
+    inner = tuple(BNBackwardLink(defer=block.defer_inner[i] and bool((_DEFER_MASK >> i) & 1)) if block.fuse_inner else None
+                  for i in range(n_inner))
     pm = _premasked_out(block)
     block._link_out = BNBackwardLink() if pm else None
     return in_link, inner, block._link_out, pm
