@@ -49,6 +49,9 @@ def _conv_folded_bn(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.
     return C.fprop_gpu(x, w_f, stride, pad, res=res, relu=relu, bias=b_f)
 
 
+# Smallest weight-gradient GEMM (FLOP) that is launched on the backward side stream (ops/streams.py).
+_SIDE_STREAM_MIN_FLOP = float(os.environ.get("PDA_WGRAD_STREAM_MIN_GFLOP", "8")) * 1e9
+
 # Block-output ReLU masks travel to the consuming conv's dgrad epilogue as sign bits (BNBackwardLink.maskbits).
 _MASK_BITS = os.environ.get("PDA_RELU_MASK_BITS", "1") == "1"
 
@@ -203,7 +206,10 @@ class _ConvBnActFn(torch.autograd.Function):
         wgrad_done = False
         if ctx.needs_input_grad[1]:
             sink = C.grad_sink(weight)
-            side = streams.fork(dy.device) if sink is not None else None
+            # ... when the kernel is long enough to be worth a fork / join (two events and a stream switch cost the
+            # host ~40 us): launch-bound steps - ResNet-18 on 32x32 images - ran 1.5x slower with every wgrad forked
+            big = 2.0 * dy.numel() * R * S * Cin >= _SIDE_STREAM_MIN_FLOP
+            side = streams.fork(dy.device) if (sink is not None and big) else None
             if side is not None:
                 with torch.cuda.stream(side):
                     dwk = C.wgrad_gpu(dy, x, R, S, stride, pad, out=sink, in_affine=ctx.in_aff)
