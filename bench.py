@@ -353,6 +353,8 @@ def worker(args) -> int:
                 model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=args.bucket_mb,
                             force_comm=args.force_ddp, comm=kind, wire_dtype=args.wire_dtype)
                 comm_obj = model._coll
+                if not on_cpu:
+                    model.measure_exposed_comm(True)
                 comm_info["comm_backend"] = getattr(comm_obj, "backend", type(comm_obj).__name__)
                 if hasattr(comm_obj, "nranks"):
                     comm_info["rccl_nranks"] = comm_obj.nranks()
@@ -448,6 +450,9 @@ def worker(args) -> int:
     if ddp and args.engine == "native":  # after the arrival-order rebuild
         comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
                                  "params": b["params"]} for b in model.bucket_summary()]
+    exposed = None
+    if ddp and args.engine == "native" and not on_cpu:
+        exposed = model.exposed_comm_ms(last=args.steps)
     ips = world * B * args.steps / dt
     host_ms = 1000 * host_dt[0] / max(args.steps, 1)
     vs_stock = stock_ips = None
@@ -482,6 +487,7 @@ def worker(args) -> int:
                        "conv_autotune": backends.benchmark if args.engine == "native" else None,
                        "final_loss": round(final_loss, 4), "hip_graph": graphed,
                        "host_issue_ms_per_step": round(host_ms, 3),
+                       "exposed_comm_ms_per_step": None if exposed is None else round(exposed, 3),
                        "comm_backend": comm_info["comm_backend"], "rccl_nranks": comm_info["rccl_nranks"],
                        "wire_dtype": comm_info["wire_dtype"], "bucket_mb": comm_info["bucket_mb"],
                        "buckets": comm_info["buckets"],

@@ -142,6 +142,7 @@ class DistributedDataParallel(nn.Module):
             raise RuntimeError("DistributedDataParallel: module has no parameter that requires grad")
         self.device = self._params[0].device
         self._on_device = bool(comm.device_collectives)
+        self._exposed_probe = None
         if isinstance(wire_dtype, str):
             if wire_dtype != "auto":
                 wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": None, "none": None}[wire_dtype]
@@ -375,6 +376,10 @@ class DistributedDataParallel(nn.Module):
                 pass
             for b in self._plan.flush_unready():
                 self._launch(self._buckets[b])
+        probe = self._exposed_probe if self._on_device else None
+        if probe is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
         post = 1.0
         if self.gradient_average and not self._use_avg_op:
             post = self._pre / self.world_size
@@ -394,6 +399,12 @@ class DistributedDataParallel(nn.Module):
             elif post != 1.0:
                 bk.flat.mul_(post)
             bk.launched = False
+        if probe is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
+            probe.append((e1, e2))
+            if len(probe) > 512:
+                del probe[:256]
         order = self._plan.arrival_order() if self._rebuild_pending else None
         self._plan.reset()
         if self._rebuild_pending:
@@ -457,6 +468,22 @@ class DistributedDataParallel(nn.Module):
         for p in self.module.parameters():
             if not p.requires_grad and p.grad is not None:
                 p.grad = None
+
+    def measure_exposed_comm(self, on: bool = True) -> None:
+        """Bracket the wait for the bucket all-reduces at the end of every backward pass with two device events:
+        the time between them is communication the backward kernels did NOT hide (0 when every bucket had
+        finished before the last gradient kernel did)."""
+        self._exposed_probe = [] if on else None
+
+    def exposed_comm_ms(self, last: int = 0) -> Optional[float]:
+        """Mean exposed communication time per backward pass over the recorded (or the ``last`` n) passes;
+        synchronises the device."""
+        probe = self._exposed_probe
+        if not probe:
+            return None
+        torch.cuda.synchronize(self.device)
+        sel = probe[-last:] if last else probe
+        return sum(a.elapsed_time(b) for a, b in sel) / len(sel)
 
     def bucket_summary(self) -> List[dict]:
         wsz = torch.empty((), dtype=self.wire_dtype).element_size() if self.wire_dtype is not None else None
