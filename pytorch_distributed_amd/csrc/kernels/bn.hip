@@ -188,7 +188,8 @@ bn_finalize_kernel(float* __restrict__ psum, float* __restrict__ psq, int nparts
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out,
-                                   long long* __restrict__ num_batches_tracked, int clear) {
+                                   long long* __restrict__ num_batches_tracked, int clear,
+                                   int lp_dtype, void* __restrict__ lp_out, float* __restrict__ rt_out) {
   __shared__ typename PartialReduce<CH>::Scratch red;
   int c, pl;
   double s, q;
@@ -203,8 +204,26 @@ bn_finalize_kernel(float* __restrict__ psum, float* __restrict__ psq, int nparts
   invstd_out[c] = invstd;
   const float g = gamma ? gamma[c] : 1.f;
   const float b = beta ? beta[c] : 0.f;
-  scale_out[c] = g * invstd;
-  shift_out[c] = b - (float)mean * g * invstd;
+  const float sc = g * invstd, sf = b - (float)mean * g * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = sf;
+  if (lp_out != nullptr) {
+    // the coefficient tables of a consumer that normalises on load (see bn_lp_tables_kernel), without a launch
+    // of their own: lp[0..C) / lp[C..2C) in the activation type, rt = those rounded values back in fp32
+    if (lp_dtype == PDA_F16) {
+      const f16 s16 = (f16)sc, f16v = (f16)sf;
+      reinterpret_cast<f16*>(lp_out)[c] = s16;
+      reinterpret_cast<f16*>(lp_out)[C + c] = f16v;
+      rt_out[c] = (float)s16;
+      rt_out[C + c] = (float)f16v;
+    } else {
+      const bf16 s16 = (bf16)sc, f16v = (bf16)sf;
+      reinterpret_cast<bf16*>(lp_out)[c] = s16;
+      reinterpret_cast<bf16*>(lp_out)[C + c] = f16v;
+      rt_out[c] = (float)s16;
+      rt_out[C + c] = (float)f16v;
+    }
+  }
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -557,19 +576,39 @@ PDA_EXPORT int pda_bn_compress_partials(const float* pa, const float* pb, int np
   return pda_check_launch();
 }
 
+static int bn_finalize_impl(float* psum, float* psq, int nparts, int C, double count, float eps,
+                            float momentum, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* mean_out, float* invstd_out, float* scale_out,
+                            float* shift_out, long long* num_batches_tracked, int clear, int lp_dtype, void* lp_out,
+                            float* rt_out, hipStream_t st) {
+  if (lp_out != nullptr && lp_dtype != PDA_F16 && lp_dtype != PDA_BF16) return -6;
+  if (partial_ch(nparts, C) == 4)
+    hipLaunchKernelGGL(bn_finalize_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, psum, psq, nparts, C, count,
+                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked, clear, lp_dtype, lp_out, rt_out);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
+                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, num_batches_tracked, clear, lp_dtype, lp_out, rt_out);
+  return pda_check_launch();
+}
+
 PDA_EXPORT int pda_bn_finalize(float* psum, float* psq, int nparts, int C, double count, float eps,
                                float momentum, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float* mean_out, float* invstd_out, float* scale_out,
                                float* shift_out, long long* num_batches_tracked, int clear, hipStream_t st) {
-  if (partial_ch(nparts, C) == 4)
-    hipLaunchKernelGGL(bn_finalize_kernel<4>, dim3((C + 3) / 4), dim3(1024), 0, st, psum, psq, nparts, C, count,
-                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
-                       shift_out, num_batches_tracked, clear);
-  else
-    hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((C + 15) / 16), dim3(1024), 0, st, psum, psq, nparts, C, count,
-                       eps, momentum, gamma, beta, running_mean, running_var, mean_out, invstd_out, scale_out,
-                       shift_out, num_batches_tracked, clear);
-  return pda_check_launch();
+  return bn_finalize_impl(psum, psq, nparts, C, count, eps, momentum, gamma, beta, running_mean, running_var, mean_out,
+                          invstd_out, scale_out, shift_out, num_batches_tracked, clear, 0, nullptr, nullptr, st);
+}
+
+// pda_bn_finalize that also writes the 16-bit coefficient tables (lp_out: [2][C] of lp_dtype, rt_out: [2][C] fp32).
+PDA_EXPORT int pda_bn_finalize_lp(float* psum, float* psq, int nparts, int C, double count, float eps,
+                                  float momentum, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float* mean_out, float* invstd_out, float* scale_out,
+                                  float* shift_out, long long* num_batches_tracked, int clear, int lp_dtype,
+                                  void* lp_out, float* rt_out, hipStream_t st) {
+  return bn_finalize_impl(psum, psq, nparts, C, count, eps, momentum, gamma, beta, running_mean, running_var, mean_out,
+                          invstd_out, scale_out, shift_out, num_batches_tracked, clear, lp_dtype, lp_out, rt_out, st);
 }
 
 PDA_EXPORT int pda_bn_eval_coeffs(int C, float eps, const float* gamma, const float* beta,

@@ -120,12 +120,20 @@ class _ConvBnActFn(torch.autograd.Function):
             raise RuntimeError(
                 f"conv_bn_act: shape not supported by the MFMA kernels (Cin={Cin}, dtype={dtype}); "
                 "use nn.Conv2d + nn.BatchNorm2d modules for this layer")
+        ctx.premasked = bool(dout_premasked and relu)
+        # the consumer normalises on load (see BNBackwardLink.defer): decided here so that the finalize kernel
+        # can write the 16-bit coefficient tables in the same launch
+        defer = (out_link is not None and out_link.defer and ctx.premasked and train_stats and residual is None
+                 and x.element_size() == 2 and K % 8 == 0 and _DEFER_APPLY)
+        tables = None
         if train_stats:
             y, psum, psq = r
             M = y.numel() // K
-            mean, invstd, scale, shift, count = Nm.finalize(psum, psq, float(M), gamma, beta, st,
-                                                            clear=sbuf is not None
-                                                            and psum.data_ptr() == sbuf.data_ptr())
+            fin = Nm.finalize(psum, psq, float(M), gamma, beta, st,
+                              clear=sbuf is not None and psum.data_ptr() == sbuf.data_ptr(),
+                              lp=dtype if defer else None)
+            mean, invstd, scale, shift, count = fin[:5]
+            tables = fin[5:] if defer else None
         else:
             y = r
             scale, shift = Nm.eval_coeffs(gamma, beta, st)
@@ -133,14 +141,11 @@ class _ConvBnActFn(torch.autograd.Function):
             if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
                 mean, invstd = Nm.eval_moments(st)   # frozen statistics, trainable affine
             count = float(y.numel() // K)
-        ctx.premasked = bool(dout_premasked and relu)
-        defer = (out_link is not None and out_link.defer and ctx.premasked and train_stats and residual is None
-                 and y.element_size() == 2 and _DEFER_APPLY)
         if defer:
             # the consumer normalises on load; autograd still sees this tensor as "the activation"
             out = y
             out_link.deferred = True
-            xs, xf, rs, rf = Nm.lp_tables(scale, shift, dtype)
+            xs, xf, rs, rf = tables
             out_link.xaffine = (xs, xf)
             # the mask recomputation in the consumer's dgrad epilogue decides with the same rounded coefficients
             # as its forward did (an fp32 product and a 16-bit FMA of the same operands have the same sign)

@@ -73,11 +73,13 @@ def stats_generation() -> int:
     return _STATS_GENERATION
 
 
-def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = False):
-    """partials -> (mean, invstd, scale, shift); updates running stats in place.
+def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = False, lp: Optional[torch.dtype] = None):
+    """partials -> (mean, invstd, scale, shift, count); updates running stats in place.
 
     ``clear`` zeroes the partial rows once they have been read (persistent accumulation rows of
-    ``conv.WeightCache.stats_buffer``)."""
+    ``conv.WeightCache.stats_buffer``).  ``lp`` (fp16 / bf16): the same kernel also writes the coefficient tables
+    of a consumer that normalises on load, and the result grows by what :func:`lp_tables` returns:
+    ``(..., count, scale_lp, shift_lp, scale_rt, shift_rt)``."""
     l = _lib.lib()
     C = psum.shape[-1]
     if not clear:
@@ -111,11 +113,23 @@ def finalize(psum, psq, count: float, gamma, beta, st: BNState, clear: bool = Fa
             mom = 1.0 / float(st.num_batches_tracked.item())
         else:
             nbt = st.num_batches_tracked  # incremented by the finalize kernel itself
+    if lp is not None and C % 8 == 0:
+        lpt = torch.empty((2, C), device=dev, dtype=lp)
+        rt = torch.empty((2, C), device=dev, dtype=torch.float32)
+        _lib.check(l.pda_bn_finalize_lp(psum.data_ptr(), psq.data_ptr(), nparts, C, float(count), float(st.eps),
+                                        float(mom if mom is not None else 0.1), _lib.ptr(gamma), _lib.ptr(beta),
+                                        _lib.ptr(rm), _lib.ptr(rv), out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr(), out[3].data_ptr(), _lib.ptr(nbt), int(clear),
+                                        _lib.dt(lp), lpt.data_ptr(), rt.data_ptr(), _lib.stream()),
+                   "pda_bn_finalize_lp")
+        return out[0], out[1], out[2], out[3], count, lpt[0], lpt[1], rt[0], rt[1]
     _lib.check(l.pda_bn_finalize(psum.data_ptr(), psq.data_ptr(), nparts, C, float(count), float(st.eps),
                                  float(mom if mom is not None else 0.1), _lib.ptr(gamma), _lib.ptr(beta),
                                  _lib.ptr(rm), _lib.ptr(rv), out[0].data_ptr(), out[1].data_ptr(),
                                  out[2].data_ptr(), out[3].data_ptr(), _lib.ptr(nbt), int(clear), _lib.stream()),
                "pda_bn_finalize")
+    if lp is not None:
+        return (out[0], out[1], out[2], out[3], count) + lp_tables(out[2], out[3], lp)
     return out[0], out[1], out[2], out[3], count
 
 
