@@ -59,9 +59,17 @@ class _Reducing:
         def ready():
             if p.grad is None:
                 return
+            # the gradient may have been launched on the backward side stream: enqueue the reduction from that
+            # stream (the engine orders itself after an event of the enqueuing stream), so the input-gradient
+            # chain on the main stream does not wait for weight gradients it never reads
             from ..ops import streams
-            streams.join()  # the gradient may have been launched on the backward side stream
-            self._hvd_hook(p)
+            side = streams.pending(p.grad.device) if p.grad.is_cuda else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(p.grad.device))
+                with torch.cuda.stream(side):
+                    self._hvd_hook(p)
+            else:
+                self._hvd_hook(p)
         return ready
 
     # -- gradient hooks -----------------------------------------------------------------------
