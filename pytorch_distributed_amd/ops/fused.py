@@ -56,7 +56,10 @@ _SIDE_STREAM_MIN_FLOP = float(os.environ.get("PDA_WGRAD_STREAM_MIN_GFLOP", "8"))
 _MASK_BITS = os.environ.get("PDA_RELU_MASK_BITS", "1") == "1"
 
 # Normalise-on-load between a conv+BatchNorm+ReLU and its single consumer (see BNBackwardLink.defer).
-_DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "1"
+# On by default for fp16 only: bf16 has no packed FMA, its on-load normalisation runs in fp32 and costs more than
+# the pass it saves (ResNet-50, batch 400: 34.1 vs 33.5 ms per step); PDA_DEFER_BN_APPLY=all forces it for both.
+_DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") in ("1", "all")
+_DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
 
 
 class BNBackwardLink:
@@ -124,7 +127,8 @@ class _ConvBnActFn(torch.autograd.Function):
         # the consumer normalises on load (see BNBackwardLink.defer): decided here so that the finalize kernel
         # can write the 16-bit coefficient tables in the same launch
         defer = (out_link is not None and out_link.defer and ctx.premasked and train_stats and residual is None
-                 and x.element_size() == 2 and K % 8 == 0 and _DEFER_APPLY)
+                 and (x.dtype == torch.float16 or (_DEFER_ALL_16BIT and x.element_size() == 2)) and K % 8 == 0
+                 and _DEFER_APPLY)
         tables = None
         if train_stats:
             y, psum, psq = r
