@@ -265,7 +265,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                 const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
-                int relu, unsigned char* __restrict__ mask_out) {
+                int relu, unsigned char* __restrict__ mask_out, int stream_out) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
@@ -286,7 +286,7 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
       if (relu) f = fmaxf(f, 0.f);
       o.v[e] = ElemTraits<T>::from_f32(f);
     }
-    store16_stream(out + i * EPC, o);
+    store16_maybe_stream(out + i * EPC, o, stream_out);
     if (mask_out != nullptr) {
       // one byte per 16-byte vector: bit e = element e is positive.  Whoever applies this layer's ReLU
       // backward (the dgrad epilogue of the consuming conv) reads these bits instead of the activation:
@@ -417,7 +417,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                     const float* __restrict__ coef, long long nvec, int C, int relu,
-                    T* __restrict__ dy, T* __restrict__ dres) {
+                    T* __restrict__ dy, T* __restrict__ dres, int stream_out) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -449,8 +449,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
       o.v[e] = ElemTraits<T>::from_f32(cA[e] * gd + cB[e] * yv + cK[e]);
       og.v[e] = ElemTraits<T>::from_f32(gd);
     }
-    store16_stream(dy + i * EPC, o);
-    if (dres) store16_stream(dres + i * EPC, og);
+    store16_maybe_stream(dy + i * EPC, o, stream_out);
+    if (dres) store16_maybe_stream(dres + i * EPC, og, stream_out);
   }
 }
 
@@ -668,7 +668,8 @@ static int bn_apply_impl(int dtype, const void* y, const void* res, void* out, c
   if (nvec == 0) return 0;
   const int vpr = C / (16 / es);
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
-                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu, mask_out));
+                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu, mask_out,
+                                           (int)(nvec * 16 >= pda_stream_min_bytes())));
   return pda_check_launch();
 }
 
@@ -737,6 +738,6 @@ PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, cons
   const int vpr = C / (16 / es);
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
                                            st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, relu,
-                                           (T*)dy, (T*)dres));
+                                           (T*)dy, (T*)dres, (int)(nvec * 16 >= pda_stream_min_bytes())));
   return pda_check_launch();
 }

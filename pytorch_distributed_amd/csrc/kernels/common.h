@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define PDA_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -71,6 +72,20 @@ __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
 template <typename T>
 __device__ __forceinline__ void store16_stream(T* p, const Vec16<T>& v) {
   __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(p));
+}
+// Outputs smaller than this stay on the default cache policy: the kernel that reads them next finds them in
+// L2 / the memory-side cache (PDA_STREAM_MIN_MB, default 64).
+static inline long long pda_stream_min_bytes() {
+  static const long long v = [] {
+    const char* e = getenv("PDA_STREAM_MIN_MB");
+    return (e ? atoll(e) : 64LL) << 20;
+  }();
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void store16_maybe_stream(T* p, const Vec16<T>& v, int stream) {
+  if (stream) store16_stream(p, v);
+  else store16(p, v);
 }
 template <typename T>
 __device__ __forceinline__ Vec16<T> load16_stream(const T* p) {

@@ -32,6 +32,7 @@ struct ConvArgs {
   const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res);
                     // with mask_bits: one byte per 16-byte vector of that tensor, bit e = element e is positive
   int mask_bits;
+  int stream_out;   // the output is far larger than the caches: non-temporal stores (host-decided by its size)
   // BatchNorm backward of the layer that produced this conv's input, folded into a dgrad epilogue:
   // bnc = that layer's pre-normalisation tensor [M][Co].  With bn_scale/bn_shift the layer's ReLU mask
   // (bnc*scale+shift > 0) is applied to the output; with psum/psq the per-tile column sums of the final
@@ -960,7 +961,7 @@ igemm_kernel(ConvArgs a) {
             g2[e] += vf * cf;
           }
         }
-        store16_stream(Y + o, val);
+        store16_maybe_stream(Y + o, val, a.stream_out);
       }
     }
     if (stats) __syncthreads();  // the statistics scratch below reuses the staging area
@@ -1592,6 +1593,7 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
   ConvArgs a;
   a.in_scale = in_scale; a.in_shift = in_shift;
   a.mask_bits = mask != nullptr ? mask_bits : 0;
+  a.stream_out = (long long)N * Ho * Wo * Co * (dtype == PDA_F32 ? 4 : 2) >= pda_stream_min_bytes();
   if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
   a.stat_slots = stat_slots;
   a.x = x; a.w = w; a.y = y; a.res = res; a.mask = mask; a.bnc = bnc; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
