@@ -62,7 +62,7 @@ def _apply_policy(model: torch.nn.Module, opt_level: str, dtype: torch.dtype) ->
 
 
 def _install_master_copies(model: torch.nn.Module, optimizer, dtype: torch.dtype) -> None:
-    """O2: persistent half copies of the conv weights, refreshed by the optimizer kernel."""
+    """O2: persistent half copies of the conv and linear weights, refreshed by the optimizer kernel."""
     from .. import nn as pnn
     if not hasattr(optimizer, "register_model_copy"):
         return
@@ -73,6 +73,16 @@ def _install_master_copies(model: torch.nn.Module, optimizer, dtype: torch.dtype
             cache: WeightCache = m._cache
             cache.pinned_lp = (dtype, half, m.weight._version)
             from ..ops import conv as _conv
+            _conv._PINNED_SYNCED[half.data_ptr()] = _conv.param_generation()
+            optimizer.register_model_copy(m.weight, half)
+        elif isinstance(m, pnn.Linear) and m.weight.is_cuda and m.weight.dtype == torch.float32:
+            from ..ops import conv as _conv
+            from ..ops.linear import LinearCache
+            lcache = m.__dict__.get("_pda_cache")
+            if lcache is None:
+                lcache = m.__dict__["_pda_cache"] = LinearCache()
+            half = m.weight.detach().to(dtype)
+            lcache.pinned_lp = (dtype, half, m.weight._version)
             _conv._PINNED_SYNCED[half.data_ptr()] = _conv.param_generation()
             optimizer.register_model_copy(m.weight, half)
 

@@ -62,6 +62,10 @@ struct ConvArgs {
   // way into LDS (tables of Ci values in the tensor's own 16-bit type); padding taps and rows past M stay zero
   const void* in_scale;
   const void* in_shift;
+  // split-K (pointwise fprop only, csplit > 0; the KS instantiations): workgroup (x, y) reduces channels [y * csplit, (y + 1) * csplit) and
+  // adds its partial tile into the fp32 [M][Co] matrix at `y` with float atomics - for GEMMs with so few output
+  // tiles (a Linear layer on a small batch) that one workgroup per tile would leave most of the chip idle
+  int ksplit, csplit;
   unsigned long long* stamps;              // diagnostics (PDA_IGEMM_STAMPS=1): 8 s_memtime stamps per workgroup
   int ablate;                              // diagnostics (PDA_IGEMM_ABLATE), bits: 1 = no operand loads after the
                                            // prologue, 2 = no fragment reads / MFMAs, 4 = no epilogue (results are garbage either way)
@@ -150,7 +154,7 @@ template <int ROWB> __device__ __forceinline__ int swz(int row) {
 // about that factor - the implicit-GEMM tiles above re-fetch every input pixel once per tap and run into the
 // L2 -> CU bandwidth long before the matrix pipe is busy.
 template <typename T, int BM, int BN, int ROWB, int MODE, bool EX, int WM = 2, int STAGES = 0, bool XF = false,
-          bool SL = false>
+          bool SL = false, bool KS = false>
 __global__ void __launch_bounds__(128 * WM) PDA_IGEMM_ATTR
 igemm_kernel(ConvArgs a) {
   static_assert(!XF || (MODE == MODE_FPROP && (STAGES == 0 || SL) && sizeof(T) == 2 && !EX),
@@ -453,7 +457,16 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-  const int nk = nr * ns * (a.Ci / BK);  // 0 for a parity class no tap reaches (e.g. 1x1 stride 2)
+  int nk = nr * ns * (a.Ci / BK);  // 0 for a parity class no tap reaches (e.g. 1x1 stride 2)
+  // (KS is its own instantiation: as a run-time branch in the common kernels these few lines moved the register
+  // allocation of the main loop and cost the ResNet-50 step 4 %)
+  if constexpr (KS) {
+    const int cb = blockIdx.y * a.csplit;
+    c0 = cb;
+    soA += cb * ES;
+    soB += cb * ES;
+    nk = min(a.csplit, a.Ci - cb) / BK;
+  }
 
   // MFMAs of one K step on the tiles at A_ / B_
   // (16-bit types: the 16-deep MFMA groups kk0 .. kk1-1 of the step; the DMA ring runs a step in two halves)
@@ -818,6 +831,21 @@ igemm_kernel(ConvArgs a) {
 
   PDA_STAMP(3);  // main loop done
   if (PDA_ABL(4)) return;  // diagnostics: no write-out
+  if constexpr (KS) {
+    float* __restrict__ Yf = reinterpret_cast<float*>(a.y);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+          if (row < a.M && col < a.Co) atomicAdd(Yf + (long long)row * a.Co + col, acc[i][j][g]);
+        }
+      }
+    return;
+  }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (g&3)+8*(g>>2)+4*(lane>>5)
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
@@ -1348,6 +1376,9 @@ wgrad_kernel(WgradArgs a) {
     return;
   }
   if (nsteps == 0) return;
+  // one split: this workgroup is the only writer of its dW tile, so a plain read-add-write does (several times the
+  // rate of the float atomics - the weight gradient of a Linear layer on a small batch is all write-out)
+  const bool alone = gridDim.y == 1;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1356,7 +1387,11 @@ wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int row = k0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-        if (row < a.Co && col < a.Ktot) atomicAdd(a.dw + (long long)row * a.Ktot + col, acc[i][j][g]);
+        if (row < a.Co && col < a.Ktot) {
+          float* __restrict__ d = a.dw + (long long)row * a.Ktot + col;
+          if (alone) *d += acc[i][j][g];
+          else atomicAdd(d, acc[i][j][g]);
+        }
       }
     }
 }
@@ -1453,6 +1488,7 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   constexpr int NT = 128 * WM;
   const bool ex = a.res != nullptr || a.mask != nullptr || a.bnc != nullptr;
   if (ex && sizeof(T) == 2 && a.Co % (16 / (int)sizeof(T)) != 0) return -8;
+  if (a.csplit > 0 && (a.in_scale != nullptr || dgrad != MODE_FPROP)) return -13;
   if (a.in_scale != nullptr) {
     // input normalised on load: plain forward launches of the register-staged 16-bit tiles only
     if constexpr (sizeof(T) == 2 && (STAGES == 0 || SL)) {
@@ -1475,6 +1511,14 @@ static int launch_igemm(const ConvArgs& a, int dgrad, hipStream_t st) {
   } else if (dgrad == MODE_DGRAD) {
     if (ex) PDA_IGEMM_LAUNCH(MODE_DGRAD, true, tiles);
     else PDA_IGEMM_LAUNCH(MODE_DGRAD, false, tiles);
+  } else if (a.csplit > 0) {
+    if constexpr (STAGES == 0 && !SL) {
+      if (ex) return -13;
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, ROWB, MODE_FPROP, false, WM, STAGES, false, SL, true>), dim3(tiles, a.ksplit),
+                         dim3(NT), 0, st, a);
+    } else {
+      return -13;
+    }
   } else {
     if (ex) PDA_IGEMM_LAUNCH(MODE_FPROP, true, tiles);
     else PDA_IGEMM_LAUNCH(MODE_FPROP, false, tiles);
@@ -1589,9 +1633,19 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
                            float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
                            long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
                            int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots,
-                           const void* in_scale, const void* in_shift, hipStream_t stream, int mask_bits = 0) {
+                           const void* in_scale, const void* in_shift, hipStream_t stream, int mask_bits = 0,
+                           int ksplit = 0) {
   ConvArgs a;
   a.in_scale = in_scale; a.in_shift = in_shift;
+  a.ksplit = 1; a.csplit = 0;
+  if (ksplit >= 1) {
+    if (dgrad || R != 1 || S != 1 || res != nullptr || mask != nullptr || bnc != nullptr || bn_shift != nullptr ||
+        psum != nullptr || relu || Ci % 32 != 0)
+      return -13;
+    // channel ranges in multiples of 128 elements (a whole number of K steps for every tile), none of them empty
+    a.csplit = ((Ci + ksplit - 1) / ksplit + 127) / 128 * 128;
+    a.ksplit = (Ci + a.csplit - 1) / a.csplit;
+  }
   a.mask_bits = mask != nullptr ? mask_bits : 0;
   a.stream_out = (long long)N * Ho * Wo * Co * (dtype == PDA_F32 ? 4 : 2) >= pda_stream_min_bytes();
   if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
@@ -1683,6 +1737,16 @@ PDA_EXPORT int pda_conv_igemm_maskbits(int dtype, int dgrad, const void* x, cons
   return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
                          sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
                          nullptr, stream, 1);
+}
+
+// acc[M][N] (fp32, zero or holding a value to add to) += x[M][K] * w[N][K]^T with the reduction split `ksplit` ways
+// over workgroups (float atomics): a GEMM with few output tiles and a deep K, such as the forward of a Linear
+// layer on a small batch.  cfg as for pda_conv_igemm (register-staged tiles only).
+PDA_EXPORT int pda_gemm_splitk(int dtype, const void* x, const void* w, float* acc, int M, int K, int N, int cfg,
+                               int ksplit, hipStream_t stream) {
+  if (ksplit < 1) return -13;
+  return conv_igemm_impl(dtype, 0, x, w, acc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, 1, 1, K,
+                         K, K, K, 1, 1, N, 1, 1, 1, 1, 0, 0, 0, cfg, 0, nullptr, nullptr, stream, 0, ksplit);
 }
 
 // Forward conv whose input is normalised on load: x holds the producing layer's conv output before its

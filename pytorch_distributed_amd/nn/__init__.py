@@ -243,8 +243,9 @@ class Dropout2d(Dropout):
 
 class Linear(tnn.Linear):
     """``torch.nn.Linear`` parameters, computed in the activation dtype on this package's MFMA GEMM kernels
-    (``ops/linear.py``: forward = 1x1 fprop, dX = dgrad with the class dimension zero-padded to the kernel's
-    K step, dW = split-K wgrad, db = column sums); the library GEMM only for shapes those kernels do not take."""
+    (``ops/linear.py``: forward = 1x1 fprop, split over K when the batch gives too few output tiles; dX = dgrad
+    with the class dimension zero-padded to the kernel's K step, or the split-K kernel for small batches;
+    dW = split-K wgrad, db = column sums); the library GEMM only for shapes those kernels do not take."""
 
     def forward(self, x):
         from ..ops.linear import linear, LinearCache

@@ -179,6 +179,21 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     return (y, psum, psq) if stats else y
 
 
+def gemm_splitk(x: torch.Tensor, w: torch.Tensor, ksplit: int, cfg: int = 1) -> Optional[torch.Tensor]:
+    """fp32 ``x[M, K] @ w[N, K]^T`` with the reduction spread over ``ksplit`` workgroups per output tile (float
+    atomics into a zeroed result): for GEMMs whose ``ceil(M/128) * ceil(N/128)`` output tiles alone would leave
+    most of the 256 CUs idle.  ``None`` when the kernel does not take the shape."""
+    M, K = x.shape
+    N = w.shape[0]
+    acc = torch.zeros((M, N), device=x.device, dtype=torch.float32)
+    rc = _lib.lib().pda_gemm_splitk(_lib.dt(x), x.data_ptr(), w.data_ptr(), acc.data_ptr(), M, K, N, cfg, ksplit,
+                                    _lib.stream())
+    if rc < 0:
+        return None
+    _lib.check(rc, "pda_gemm_splitk")
+    return acc
+
+
 def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], stride, pad,
               res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None,
               bn_input: Optional[torch.Tensor] = None, bn_scale: Optional[torch.Tensor] = None,

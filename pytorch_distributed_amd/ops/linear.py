@@ -4,7 +4,10 @@
 runs on the implicit-GEMM fprop kernel, the input gradient on the dgrad kernel (the transposed weight is
 zero-padded along the reduction dimension to a multiple of the kernel's K step: 1000 classes -> 1024), the
 weight gradient on the split-K wgrad kernel (accumulating straight into ``weight.grad`` when the parameter
-allows it) and the bias gradient on the column-sum kernel.  What the reference reaches through
+allows it) and the bias gradient on the column-sum kernel.  A small batch under a deep reduction (the
+classifier layers of AlexNet / VGG: 128 x 25088 x 4096) has only a few dozen output tiles for 256 CUs: there
+the forward splits K over workgroups (``conv.gemm_splitk``) and the input gradient runs as a split-K
+"weight gradient" whose pixels are the N outputs, which also reads the weight as it is stored.  What the reference reaches through
 ``nn.Linear`` inside torchvision's ResNets (/root/reference/2.distributed.py:213) and in the MNIST net
 (/root/reference/5.2.horovod_pytorch_mnist.py:42-43).  Shapes the MFMA kernels do not take (a reduction
 dimension that is not a multiple of 32 half / 16 float elements, e.g. the 50 -> 10 layer) and CPU tensors use
@@ -12,6 +15,7 @@ the library GEMM.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -23,26 +27,56 @@ from .. import backends
 
 
 class LinearCache:
-    """Low-precision weight and its zero-padded transpose, rebuilt only when the parameter changed."""
-    __slots__ = ("key", "w_lp", "w_t")
+    """Low-precision weight and (built on first use) its zero-padded transpose, rebuilt only when the parameter
+    changed."""
+    __slots__ = ("key", "w_lp", "w_t", "pinned_lp")
 
     def __init__(self):
         self.key = None
         self.w_lp = None
         self.w_t = None
+        self.pinned_lp = None   # (dtype, tensor, torch version): 16-bit copy the optimizer kernel keeps current (amp O2)
 
-    def get(self, weight: torch.Tensor, dtype: torch.dtype, step: int):
+    def get(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, C.param_generation(), dtype)
         if self.key != key:
             w = weight.detach()
-            N, K = w.shape
-            self.w_lp = w if w.dtype == dtype else w.to(dtype)
+            pin = self.pinned_lp
+            if w.dtype == dtype:
+                lp = w
+            elif pin is not None and pin[0] == dtype and pin[1].device == w.device and pin[1].shape == w.shape:
+                lp = pin[1]
+                # stale when the master changed through torch (version counter) or through a raw kernel other than
+                # the optimizer that owns this copy (parameter broadcast: generation counter)
+                if pin[2] != weight._version or C._PINNED_SYNCED.get(lp.data_ptr()) != C.param_generation():
+                    lp.copy_(w)
+                    self.pinned_lp = (dtype, lp, weight._version)
+                    C._PINNED_SYNCED[lp.data_ptr()] = C.param_generation()
+            else:
+                lp = w.to(dtype)
+            self.w_lp = lp
+            self.w_t = None
+            self.key = key
+        return self.w_lp
+
+    def transposed(self, step: int) -> torch.Tensor:
+        """``[K][Np]`` copy of the weight last returned by :meth:`get` (dgrad's "CRSK" weight with R = S = 1),
+        ``Np`` = N rounded up to the kernel's reduction step."""
+        if self.w_t is None:
+            N, K = self.w_lp.shape
             Np = (N + step - 1) // step * step
-            wt = torch.zeros((K, Np), device=w.device, dtype=dtype)       # [K][Np]: dgrad's "CRSK" weight, R=S=1
+            wt = torch.zeros((K, Np), device=self.w_lp.device, dtype=self.w_lp.dtype)
             wt[:, :N].copy_(self.w_lp.t())
             self.w_t = wt
-            self.key = key
-        return self.w_lp, self.w_t
+        return self.w_t
+
+
+# input gradients of batches up to this many rows go through the split-K kernel (see _LinearFn.backward)
+_SPLITK_MAX_BATCH = int(os.environ.get("PDA_LINEAR_SPLITK_MAX_BATCH", "512"))
+
+
+# forward: workgroups a split-K launch aims for (0 = never split)
+_SPLITK_WORKGROUPS = int(os.environ.get("PDA_LINEAR_SPLITK_WORKGROUPS", "256"))
 
 
 def _kstep(dtype: torch.dtype) -> int:
@@ -63,18 +97,27 @@ class _LinearFn(torch.autograd.Function):
         x = x.contiguous()
         B, K = x.shape
         N = weight.shape[0]
-        step = _kstep(x.dtype)
-        w_lp, w_t = cache.get(weight, x.dtype, step)
-        y = C.fprop_gpu(x.view(B, 1, 1, K), w_lp.view(N, 1, 1, K), (1, 1), (0, 0))
+        w_lp = cache.get(weight, x.dtype)
+        y = None
+        tiles = ((B + 127) // 128) * ((N + 127) // 128)
+        if tiles * 2 <= _SPLITK_WORKGROUPS and K >= 2048 and _SPLITK_WORKGROUPS > 0:
+            # few output tiles under a deep reduction: split K over enough workgroups to fill the chip
+            ksplit = min(_SPLITK_WORKGROUPS // tiles, K // 256)
+            acc = C.gemm_splitk(x, w_lp, ksplit)
+            if acc is not None:
+                y = acc.to(x.dtype)
         if y is None:
-            raise RuntimeError("linear: the GEMM kernel refused a shape that supported() accepted")
-        y = y.view(B, N)
+            y = C.fprop_gpu(x.view(B, 1, 1, K), w_lp.view(N, 1, 1, K), (1, 1), (0, 0))
+            if y is None:
+                raise RuntimeError("linear: the GEMM kernel refused a shape that supported() accepted")
+            y = y.view(B, N)
         if bias is not None:
             l = _lib.lib()
             _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), N, 0,
                                       _lib.stream()), "pda_bias_add")
         ctx.save_for_backward(x, weight)
-        ctx.w_t = w_t
+        ctx.w_lp = w_lp
+        ctx.cache = cache
         ctx.has_bias = bias is not None
         return y
 
@@ -88,10 +131,24 @@ class _LinearFn(torch.autograd.Function):
             dy = dy.to(x.dtype)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            Np = ctx.w_t.shape[1]
-            dyp = dy if Np == N else F.pad(dy, (0, Np - N))
-            dx = C.dgrad_gpu(dyp.view(B, 1, 1, Np), ctx.w_t.view(K, 1, 1, Np), (1, 1), (1, 1), (0, 0))
-            dx = dx.view(B, K) if dx is not None else dy.float().matmul(weight.float()).to(x.dtype)
+            vec = 16 // x.element_size()
+            if B <= _SPLITK_MAX_BATCH and B % vec == 0:
+                # few rows: dX[B][K] = sum over n of dY^T[n][B] (x) W[n][K] has the shape of a weight gradient with
+                # the N outputs as its "pixels", so the split-K kernel fills the chip where the dgrad kernel would
+                # launch ceil(B/128) x ceil(K/128) tiles - and it reads the weight as it is stored: no transposed
+                # copy to rebuild after every optimizer step
+                acc = C.wgrad_gpu(dy.t().contiguous().view(N, 1, 1, B), ctx.w_lp.view(N, 1, 1, K), 1, 1, (1, 1), (0, 0))
+                if acc is not None:
+                    dx = acc.view(B, K).to(x.dtype)
+            if dx is None:
+                if ctx.cache.w_lp is not ctx.w_lp:           # the parameter changed between forward and backward
+                    ctx.cache = LinearCache()
+                    ctx.cache.w_lp = ctx.w_lp
+                w_t = ctx.cache.transposed(_kstep(x.dtype))
+                Np = w_t.shape[1]
+                dyp = dy if Np == N else F.pad(dy, (0, Np - N))
+                dx = C.dgrad_gpu(dyp.view(B, 1, 1, Np), w_t.view(K, 1, 1, Np), (1, 1), (1, 1), (0, 0))
+                dx = dx.view(B, K) if dx is not None else dy.float().matmul(weight.float()).to(x.dtype)
         if ctx.needs_input_grad[1]:
             sink = None
             g = weight.grad

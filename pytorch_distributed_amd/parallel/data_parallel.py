@@ -301,6 +301,8 @@ def replicate(module: nn.Module, devices: Sequence) -> List[nn.Module]:
                 c._buffers[k] = None if b is None else bcopies[di][bidx[id(b)]]
             if hasattr(m, "_cache"):  # per-replica low-precision weight caches
                 c._cache = type(m._cache)()
+            if "_pda_cache" in c.__dict__:  # (Linear: same)
+                c.__dict__["_pda_cache"] = type(m.__dict__["_pda_cache"])()
         replicas.append(copies[0])
     return replicas
 

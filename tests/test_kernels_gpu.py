@@ -899,13 +899,14 @@ def test_kernel_library_is_loaded():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_linear_runs_on_the_conv_gemm_kernels(dtype):
-    """nn.Linear forward / dX / dW / db on fprop / dgrad (class dimension zero-padded) / wgrad / colsum vs an fp32
-    reference on the same (rounded) inputs; shapes: the ResNet head, the MNIST fc1, a batch that is no tile multiple."""
+    """nn.Linear forward / dX / dW / db on fprop / split-K (small batches) or dgrad (class dimension zero-padded) /
+    wgrad / colsum vs an fp32 reference on the same (rounded) inputs; shapes: the ResNet head, the MNIST fc1, a batch
+    that is no tile multiple, a batch past the split-K limit."""
     from pytorch_distributed_amd.ops import linear as L
     from pytorch_distributed_amd import nn as pnn
     torch.manual_seed(61)
     tol = {torch.float32: 2e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
-    for B, K, N in ((64, 2048, 1000), (33, 320, 48), (400, 512, 1000)):
+    for B, K, N in ((64, 2048, 1000), (33, 320, 48), (400, 512, 1000), (640, 256, 1000)):
         lin = pnn.Linear(K, N).to(DEV)
         x = torch.randn(B, K, device=DEV).to(dtype).requires_grad_(True)
         assert L.supported(x, lin.weight), (B, K, N, dtype)
@@ -928,6 +929,23 @@ def test_linear_runs_on_the_conv_gemm_kernels(dtype):
     x = torch.randn(7, 50, device=DEV)
     assert not L.supported(x, lin.weight)
     assert rel_err(lin(x), F.linear(x, lin.weight, lin.bias)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_gemm_split_k(dtype):
+    """x @ w^T with the reduction split over workgroups (the forward of a Linear layer on a small batch) vs an
+    fp32 matmul of the same rounded operands: even splits, a ragged last split, a K of 32-element steps, rows and
+    columns that are no tile multiple, every register-staged tile."""
+    from pytorch_distributed_amd.ops import conv as C
+    torch.manual_seed(67)
+    tol = {torch.float32: 2e-4, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    for M, K, N, ks, cfg in ((128, 4096, 512, 8, 1), (40, 2112, 1000, 4, 1), (72, 2080, 264, 4, 2), (128, 1024, 256, 3, 3),
+                             (300, 2048, 128, 16, 9), (16, 512, 64, 64, 1)):
+        x = torch.randn(M, K, device=DEV).to(dtype)
+        w = (torch.randn(N, K, device=DEV) / K ** 0.5).to(dtype)
+        acc = C.gemm_splitk(x, w, ks, cfg)
+        assert acc is not None and acc.dtype == torch.float32, (M, K, N, ks, cfg)
+        assert rel_err(acc, x.float() @ w.float().t()) < tol, (M, K, N, ks, cfg)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
