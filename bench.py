@@ -250,11 +250,15 @@ def worker(args) -> int:
         print(json.dumps({"error": f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} "
                                    "GPU(s) visible"}), flush=True)
         return 2
+    cpu_binding = None
     if on_cpu:
         dev = torch.device("cpu")
     else:
         torch.cuda.set_device(local_rank)      # before anything else touches the device
         dev = torch.device("cuda", local_rank)
+        from pytorch_distributed_amd.utils.affinity import bind_to_gpu
+        bound = bind_to_gpu(local_rank)        # host thread (and the threads it starts) on the GPU's NUMA node
+        cpu_binding = None if bound is None else f"{len(bound)} CPUs local to the GPU"
     deadline = Deadline(args.stage_timeout, rank)
     import torch.distributed as dist
     from pytorch_distributed_amd import comm as pcomm
@@ -485,7 +489,7 @@ def worker(args) -> int:
                                                                      "not a result)" if share_gpu and world > 1 else "")),
                        "weights": "random-init",
                        "conv_autotune": backends.benchmark if args.engine == "native" else None,
-                       "final_loss": round(final_loss, 4), "hip_graph": graphed,
+                       "final_loss": round(final_loss, 4), "hip_graph": graphed, "cpu_binding": cpu_binding,
                        "host_issue_ms_per_step": round(host_ms, 3),
                        "exposed_comm_ms_per_step": None if exposed is None else round(exposed, 3),
                        "comm_backend": comm_info["comm_backend"], "rccl_nranks": comm_info["rccl_nranks"],

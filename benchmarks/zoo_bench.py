@@ -18,7 +18,7 @@ from pytorch_distributed_amd.optim import FusedSGD
 DEFAULT = "resnet18,resnet50,wide_resnet50_2,resnext50_32x4d,vgg16,vgg16_bn,alexnet,squeezenet1_1,densenet121,mobilenet_v2,shufflenet_v2_x1_0,mnasnet1_0,googlenet,inception_v3"
 
 
-def run(arch: str, batch: int, steps: int, warmup: int, size: int) -> float:
+def run(arch: str, batch: int, steps: int, warmup: int, size: int, graph: bool = False) -> float:
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = models.get_model(arch).to(dev)
@@ -36,6 +36,12 @@ def run(arch: str, batch: int, steps: int, warmup: int, size: int) -> float:
         return loss
     for _ in range(warmup):
         step()
+    if graph:
+        # the whole step (forward, loss scaling, backward, fused optimizer) recorded once and replayed as a hipGraph
+        from pytorch_distributed_amd.utils.graph import GraphedStep
+        step = GraphedStep(step, warmup=0, device=dev)
+        for _ in range(2):
+            step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -54,11 +60,12 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=6)
     p.add_argument("--out", default="")
+    p.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
     a = p.parse_args()
     backends.benchmark = True
     for arch in a.archs.split(","):
-        ips = run(arch, a.batch, a.steps, a.warmup, a.size)
-        line = f"{arch:18s} batch {a.batch:4d}  {a.size}x{a.size}  fp16 O2  {ips:10.1f} img/s  {1000 * a.batch / ips:8.2f} ms/step"
+        ips = run(arch, a.batch, a.steps, a.warmup, a.size, a.graph)
+        line = f"{arch:18s} batch {a.batch:4d}  {a.size}x{a.size}  fp16 O2{' graph' if a.graph else ''}  {ips:10.1f} img/s  {1000 * a.batch / ips:8.2f} ms/step"
         print(line, flush=True)
         if a.out:
             with open(a.out, "a") as f:

@@ -23,6 +23,7 @@ def main():
     device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        utils.bind_to_gpu(device.index)   # host threads on the GPU's NUMA node
     if info.rank == 0:
         print("=> creating model '{}'".format(args.arch))
     model = engine.make_model(args, device)

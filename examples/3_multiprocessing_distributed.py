@@ -17,6 +17,7 @@ def main_worker(local_rank, nprocs, args):
     device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        utils.bind_to_gpu(device.index)   # host threads on the GPU's NUMA node
     model = engine.make_model(args, device)
     optimizer = engine.make_optimizer(args, model)
     model, optimizer = engine.setup_amp(args, model, optimizer)

@@ -26,6 +26,7 @@ def main():
     device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        utils.bind_to_gpu(device.index)   # host threads on the GPU's NUMA node
     model = engine.make_model(args, device)
     optimizer = engine.make_optimizer(args, model)
     level = args.opt_level or "O1"

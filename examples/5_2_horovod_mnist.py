@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 import pytorch_distributed_amd.hvd as hvd
-from pytorch_distributed_amd import models
+from pytorch_distributed_amd import models, utils
 from pytorch_distributed_amd.data import DistributedSampler, mnist
 
 parser = argparse.ArgumentParser(description="MNIST Example (Horovod-style API)")
@@ -47,6 +47,7 @@ def main():
     torch.manual_seed(args.seed)
     if args.cuda:
         torch.cuda.set_device(hvd.local_rank())
+        utils.bind_to_gpu(hvd.local_rank())   # host threads on the GPU's NUMA node
         torch.cuda.manual_seed(args.seed)
     torch.set_num_threads(1)
     device = torch.device("cuda", hvd.local_rank()) if args.cuda else torch.device("cpu")

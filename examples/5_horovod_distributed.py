@@ -24,6 +24,7 @@ def main():
     device = torch.device("cuda", hvd.local_rank()) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        utils.bind_to_gpu(device.index)   # host threads on the GPU's NUMA node
     model = engine.make_model(args, device)
     per_rank = int(args.batch_size / hvd.size())
     hvd.broadcast_parameters(model.state_dict(), root_rank=0)

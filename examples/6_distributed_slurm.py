@@ -32,6 +32,7 @@ def main_worker(gpu, ngpus_per_node, args):
     device = torch.device("cuda", gpu) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
+        utils.bind_to_gpu(device.index)   # host threads on the GPU's NUMA node
     model = engine.make_model(args, device)
     optimizer = engine.make_optimizer(args, model)
     model, optimizer = engine.setup_amp(args, model, optimizer)

@@ -228,3 +228,37 @@ def test_c10d_store_adapter_outlives_init_process_group():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_cpu_binding_next_to_the_gpu(tmp_path, monkeypatch):
+    """bind_to_gpu: cpulist parsing, binding to the intersection of the GPU's local CPUs with what the process
+    may use, and the cases in which it leaves the affinity alone."""
+    import os
+    from pytorch_distributed_amd.utils import affinity as A
+    assert A.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert A.parse_cpulist("") == set()
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 5:
+        pytest.skip("needs at least 5 usable CPUs")
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    half = allowed[:len(allowed) - 1]
+    (dev / "local_cpulist").write_text(",".join(str(c) for c in half) + ",4096-4099\n")
+    monkeypatch.setattr(A, "gpu_pci_address", lambda index: "0000:c1:00.0")
+    assert A.gpu_local_cpus(0, sysfs=str(tmp_path)) == set(half) | {4096, 4097, 4098, 4099}
+    real = A.gpu_local_cpus
+    monkeypatch.setattr(A, "gpu_local_cpus", lambda index: real(index, sysfs=str(tmp_path)))
+    try:
+        assert A.bind_to_gpu(0) == set(half)
+        assert os.sched_getaffinity(0) == set(half)
+        assert A.bind_to_gpu(0) is None                  # already there: nothing to change
+        (dev / "local_cpulist").write_text(f"{allowed[0]}\n")
+        assert A.bind_to_gpu(0) is None                  # too few CPUs in common: a cpuset wins over the topology
+        monkeypatch.setenv("PDA_BIND_CPU", "0")
+        (dev / "local_cpulist").write_text(",".join(str(c) for c in half[:-1]) + "\n")
+        assert A.bind_to_gpu(0) is None
+        monkeypatch.delenv("PDA_BIND_CPU")
+        monkeypatch.setattr(A, "gpu_pci_address", lambda index: None)   # torch does not know the PCI address
+        assert real(0, sysfs=str(tmp_path)) is None
+    finally:
+        os.sched_setaffinity(0, set(allowed))
