@@ -261,11 +261,12 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict_
 
 // Every thread keeps one 16-byte channel vector for the whole grid-stride loop
 // (the stride is a multiple of the vectors per row), so scale/shift live in registers.
-template <typename T>
+// CAP (compile time): the activation is a ReLU clipped at `cap` (ReLU6); the plain instantiations are unchanged.
+template <typename T, bool CAP = false>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                 const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
-                int relu, unsigned char* __restrict__ mask_out, int stream_out) {
+                int relu, unsigned char* __restrict__ mask_out, int stream_out, float cap = 0.f) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
@@ -284,6 +285,7 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
       float f = ElemTraits<T>::to_f32(v.v[e]) * sc[e] + sf[e];
       if (res) f += ElemTraits<T>::to_f32(rv.v[e]);
       if (relu) f = fmaxf(f, 0.f);
+      if (CAP) f = fminf(f, cap);
       o.v[e] = ElemTraits<T>::from_f32(f);
     }
     store16_maybe_stream(out + i * EPC, o, stream_out);
@@ -303,12 +305,13 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 // recomputed from y*scale+shift which is exact when there was no residual).
 // MASK (compile time, so that no load sits behind a run-time branch): 0 = no ReLU, 1 = mask
 // recomputed from y, 2 = mask read from `out`.
-template <typename T, int MASK>
+// CAP: the ReLU was clipped at `cap`; values at or above it pass no gradient either.
+template <typename T, int MASK, bool CAP = false>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                      const float* __restrict__ mean, const float* __restrict__ invstd,
                      const float* __restrict__ scale, const float* __restrict__ shift, long long M, int C,
-                     int relu, float* __restrict__ pdg, float* __restrict__ pdb, int slots) {
+                     int relu, float* __restrict__ pdg, float* __restrict__ pdb, int slots, float cap = 0.f) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ float red[2][256 * EPC];
   ColGeom<T> g(C, blockIdx.y);
@@ -336,8 +339,14 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
       for (int e = 0; e < EPC; ++e) {
         float gd = ElemTraits<T>::to_f32(vd.v[e]);
         const float yv = ElemTraits<T>::to_f32(vy.v[e]);
-        if (MASK == 2) gd = ElemTraits<T>::to_f32(vo.v[e]) > 0.f ? gd : 0.f;
-        if (MASK == 1) gd = (yv * sc[e] + sf[e] > 0.f) ? gd : 0.f;
+        if (MASK == 2) {
+          const float ov = ElemTraits<T>::to_f32(vo.v[e]);
+          gd = (ov > 0.f && (!CAP || ov < cap)) ? gd : 0.f;
+        }
+        if (MASK == 1) {
+          const float fv = yv * sc[e] + sf[e];
+          gd = (fv > 0.f && (!CAP || fv < cap)) ? gd : 0.f;
+        }
         db[e] += gd;
         dg[e] += gd * yv;
       }
@@ -413,11 +422,11 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
 // dy = A[c]*g + B[c]*y + K[c]  with the three per-channel coefficients prepared by
 // bn_bwd_coefs_kernel (algebraically gamma*invstd*(g - dbeta/M - xhat*dgamma/M));
 // coef = [5][C] = {A, B, K, scale, shift}, all held in registers (see bn_apply_kernel).
-template <typename T>
+template <typename T, bool CAP = false>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                     const float* __restrict__ coef, long long nvec, int C, int relu,
-                    T* __restrict__ dy, T* __restrict__ dres, int stream_out) {
+                    T* __restrict__ dy, T* __restrict__ dres, int stream_out, float cap = 0.f) {
   constexpr int EPC = 16 / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -443,7 +452,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
       float gd = ElemTraits<T>::to_f32(vd.v[e]);
       const float yv = ElemTraits<T>::to_f32(vy.v[e]);
       if (relu) {
-        const bool pos = out ? (ElemTraits<T>::to_f32(vo.v[e]) > 0.f) : (yv * sc[e] + sf[e] > 0.f);
+        const float fv = out ? ElemTraits<T>::to_f32(vo.v[e]) : yv * sc[e] + sf[e];
+        const bool pos = fv > 0.f && (!CAP || fv < cap);
         gd = pos ? gd : 0.f;
       }
       o.v[e] = ElemTraits<T>::from_f32(cA[e] * gd + cB[e] * yv + cK[e]);
@@ -678,6 +688,20 @@ PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out
   return bn_apply_impl(dtype, y, res, out, scale, shift, M, C, relu, nullptr, st);
 }
 
+// out = min(relu(y * scale + shift + res), cap): BatchNorm + clipped ReLU (ReLU6) in one pass.
+PDA_EXPORT int pda_bn_apply_cap(int dtype, const void* y, const void* res, void* out, const float* scale,
+                                const float* shift, long long M, int C, float cap, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const long long nvec = M * C / (16 / es);
+  if (nvec == 0) return 0;
+  const int vpr = C / (16 / es);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, true>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
+                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, 1,
+                                           (unsigned char*)nullptr, (int)(nvec * 16 >= pda_stream_min_bytes()), cap));
+  return pda_check_launch();
+}
+
 // As pda_bn_apply, and mask_out[i] (one byte per 16-byte vector of `out`, M*C*sizeof(T)/16 bytes) gets the
 // "element is positive" bits of vector i.
 PDA_EXPORT int pda_bn_apply_mask(int dtype, const void* y, const void* res, void* out, const float* scale,
@@ -702,6 +726,24 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
   else if (mask == 1) { PDA_BWD_REDUCE(1); }
   else { PDA_BWD_REDUCE(2); }
 #undef PDA_BWD_REDUCE
+  return pda_check_launch();
+}
+
+// pda_bn_bwd_reduce for a ReLU clipped at `cap`: elements at or above the cap pass no gradient.
+PDA_EXPORT int pda_bn_bwd_reduce_cap(int dtype, const void* dout, const void* y, const void* out, const float* mean,
+                                     const float* invstd, const float* scale, const float* shift, long long M, int C,
+                                     float cap, float* pdg, float* pdb, int slots, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const int nb = pda_bn_num_partials(M, C, dtype);
+#define PDA_BWD_REDUCE_CAP(MASK)                                                                                     \
+  PDA_DISPATCH_T(dtype,                                                                                              \
+                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, true>), dim3(nb, col_blocks_y(C, es)), dim3(256), \
+                                    0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift,   \
+                                    M, C, 1, pdg, pdb, slots, cap))
+  if (out == nullptr) { PDA_BWD_REDUCE_CAP(1); }
+  else { PDA_BWD_REDUCE_CAP(2); }
+#undef PDA_BWD_REDUCE_CAP
   return pda_check_launch();
 }
 
@@ -739,5 +781,19 @@ PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, cons
   PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
                                            st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, relu,
                                            (T*)dy, (T*)dres, (int)(nvec * 16 >= pda_stream_min_bytes())));
+  return pda_check_launch();
+}
+
+// pda_bn_bwd_apply for a ReLU clipped at `cap`.
+PDA_EXPORT int pda_bn_bwd_apply_cap(int dtype, const void* dout, const void* y, const void* out, const float* coef,
+                                    long long M, int C, float cap, void* dy, void* dres, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if (C % (16 / es) != 0) return -1;
+  const long long nvec = M * C / (16 / es);
+  if (nvec == 0) return 0;
+  const int vpr = C / (16 / es);
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
+                                           st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, 1,
+                                           (T*)dy, (T*)dres, (int)(nvec * 16 >= pda_stream_min_bytes()), cap));
   return pda_check_launch();
 }

@@ -4,7 +4,7 @@
 ``state_dict()`` keys are torchvision's (``features.0.0.weight``, ``features.2.conv.1.0.weight`` - the
 depthwise ``[C, 1, 3, 3]`` filter -, ``features.18.1.running_mean``, ``classifier.1.weight``).  The 1x1
 expand / project convolutions run as fused conv + BatchNorm on the MFMA kernels, the 3x3 depthwise
-convolution on the vector-memory depthwise kernels, ReLU6 as its own clipped-activation kernel.
+convolution on the vector-memory depthwise kernels, ReLU6 folded into the BatchNorm passes as a clipped ReLU.
 """
 from __future__ import annotations
 
@@ -31,7 +31,8 @@ class ConvBNReLU(tnn.Sequential):
                          pnn.BatchNorm2d(cout), pnn.ReLU6())
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.relu6(pnn.ConvBnAct.run(self[0], self[1], x, relu=False))
+        # ReLU6 rides in the BatchNorm passes (forward clip, backward mask): no activation kernel of its own
+        return pnn.ConvBnAct.run(self[0], self[1], x, relu=6.0)
 
 
 class InvertedResidual(tnn.Module):

@@ -58,6 +58,9 @@ _SIGS = {
     "pda_bn_finalize": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "pda_bn_finalize_lp": [c_p, c_p, c_i, c_i, c_d, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "pda_bn_eval_coeffs": [c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "pda_bn_apply_cap": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_p],
+    "pda_bn_bwd_reduce_cap": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_p, c_p, c_i, c_p],
+    "pda_bn_bwd_apply_cap": [c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_p, c_p, c_p],
     "pda_bn_apply": [c_i, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_bn_bwd_reduce": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p, c_p, c_i, c_p],
     "pda_bn_bwd_finalize": [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_i, c_i, c_p],

@@ -46,7 +46,10 @@ def _conv_folded_bn(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.
     vers += (Nm.stats_generation(), st.running_mean.data_ptr(), float(st.eps))
     w_f, b_f = cache.folded(weight, x.dtype, vers, lambda: Nm.eval_coeffs(gamma, beta, st))
     res = residual.contiguous() if residual is not None else None
-    return C.fprop_gpu(x, w_f, stride, pad, res=res, relu=relu, bias=b_f)
+    o = C.fprop_gpu(x, w_f, stride, pad, res=res, relu=bool(relu), bias=b_f)
+    if o is not None and Nm.relu_cap(relu) is not None:
+        o.clamp_(max=Nm.relu_cap(relu))
+    return o
 
 
 # Smallest weight-gradient GEMM (FLOP) that is launched on the backward side stream (ops/streams.py).
@@ -203,7 +206,7 @@ class _ConvBnActFn(torch.autograd.Function):
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
                                            has_res, group, ctx.beta, cache.stats_buffer(K, dout.device))
         else:
-            g = dout if (not relu or ctx.premasked) else dout * (mask_src > 0).to(dout.dtype)
+            g = dout if (not relu or ctx.premasked) else dout * Nm.relu_mask(mask_src, relu).to(dout.dtype)
             dy = (g.float() * scale).to(dout.dtype)
             dres = g if has_res else None
             dg = db = None
@@ -287,11 +290,15 @@ class _ConvBnActFn(torch.autograd.Function):
         return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
+def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNState,
                 cache: Optional[C.WeightCache] = None, passthrough: bool = False, mask_dx: bool = False,
                 dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
                 out_link: Optional[BNBackwardLink] = None):
     """NHWC fused conv + BatchNorm (+residual) (+ReLU).
+
+    ``relu``: ``False``, ``True``, or a positive number ``c`` for a ReLU clipped at ``c`` (ReLU6: ``relu=6.0``),
+    applied and differentiated inside the BatchNorm passes like the plain one; a clipped activation takes no
+    part in the mask / link hand-offs below, which describe ``x > 0`` only.
 
     ``passthrough=True`` returns ``(out, x_alias)``: feed ``x_alias`` to the other consumer of ``x``
     (the residual branch of a ResNet block) and its gradient is summed inside this op's dgrad
@@ -309,6 +316,8 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu: bool, st: N
     and the single consumer of its output, through which the consumer's dgrad epilogue also delivers the
     reductions of this op's BatchNorm backward.  A consumer given ``in_link`` always applies the
     producer's ReLU mask, so the pair stays correct when the sums cannot be produced."""
+    if Nm.relu_cap(relu) is not None and (dout_premasked or out_link is not None):
+        raise ValueError("conv_bn_act: a clipped ReLU cannot hand its mask to the consumer (dout_premasked / out_link)")
     if not x.is_cuda:
         # reference path: the ReLU masks its own gradient, so both hints can be ignored together
         y = C.conv2d_ref(x, weight, None, stride, pad)

@@ -172,7 +172,21 @@ def eval_affine_grads(g: torch.Tensor, y: torch.Tensor, mean: torch.Tensor, invs
     return (gf * ((y.float() - mean) * invstd)).sum(dims), gf.sum(dims)
 
 
-def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool, want_mask: bool = False):
+def relu_cap(relu) -> Optional[float]:
+    """The activation argument of this module is ``False`` (none), ``True`` (ReLU) or a positive number ``c``
+    (ReLU clipped at ``c``: ``min(max(v, 0), c)``, ReLU6 for ``c = 6``); returns ``c`` for the last form."""
+    if relu is True or relu is False or relu is None or not relu:
+        return None
+    return float(relu)
+
+
+def relu_mask(out: torch.Tensor, relu) -> torch.Tensor:
+    """Where the activation ``relu`` (see :func:`relu_cap`) that produced ``out`` passes a gradient."""
+    cap = relu_cap(relu)
+    return (out > 0) if cap is None else ((out > 0) & (out < cap))
+
+
+def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu, want_mask: bool = False):
     """``relu(y * scale + shift + res)``.  ``want_mask``: also return the sign bits of the result, one byte per
     16-byte vector (bit e = element e is positive): what the ReLU backward needs of this tensor, at 1/16 of its
     size (``conv.dgrad_gpu(mask=..., mask_bits=True)``)."""
@@ -180,6 +194,13 @@ def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu: bool
     C = y.shape[-1]
     M = y.numel() // C
     out = torch.empty_like(y)
+    cap = relu_cap(relu)
+    if cap is not None:
+        if want_mask:
+            raise ValueError("norm.apply: sign-bit masks describe a plain ReLU, not a clipped one")
+        _lib.check(l.pda_bn_apply_cap(_lib.dt(y), y.data_ptr(), _lib.ptr(res), out.data_ptr(), scale.data_ptr(),
+                                      shift.data_ptr(), M, C, cap, _lib.stream()), "pda_bn_apply_cap")
+        return out
     if want_mask:
         bits = torch.empty(y.numel() * y.element_size() // 16, device=y.device, dtype=torch.uint8)
         _lib.check(l.pda_bn_apply_mask(_lib.dt(y), y.data_ptr(), _lib.ptr(res), out.data_ptr(), scale.data_ptr(),
@@ -201,7 +222,7 @@ def _vec_sink(param):
     return g
 
 
-def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu: bool, want_dres: bool,
+def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu, want_dres: bool,
              group=None, beta=None, scratch=None, presums=None):
     """-> dy, dres (or None), dgamma, dbeta.
 
@@ -229,7 +250,13 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
     else:
         part = torch.empty((2, n, C), device=dev, dtype=torch.float32)
         pdg, pdb = part[0], part[1]
-    if presums is None:
+    cap = relu_cap(relu)
+    if presums is None and cap is not None:
+        _lib.check(l.pda_bn_bwd_reduce_cap(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask),
+                                           mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M,
+                                           C, cap, pdg.data_ptr(), pdb.data_ptr(), slots, _lib.stream()),
+                   "pda_bn_bwd_reduce_cap")
+    elif presums is None:
         _lib.check(l.pda_bn_bwd_reduce(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask),
                                        mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), M, C,
                                        int(relu), pdg.data_ptr(), pdb.data_ptr(), slots, _lib.stream()),
@@ -256,8 +283,14 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                                       coef.data_ptr(), _lib.stream()), "pda_bn_bwd_coefs")
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask), coef.data_ptr(),
-                                  M, C, int(relu), dy.data_ptr(), _lib.ptr(dres), _lib.stream()), "pda_bn_bwd_apply")
+    if cap is not None:
+        _lib.check(l.pda_bn_bwd_apply_cap(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask),
+                                          coef.data_ptr(), M, C, cap, dy.data_ptr(), _lib.ptr(dres), _lib.stream()),
+                   "pda_bn_bwd_apply_cap")
+    else:
+        _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), _lib.ptr(out_for_mask),
+                                      coef.data_ptr(), M, C, int(relu), dy.data_ptr(), _lib.ptr(dres), _lib.stream()),
+                   "pda_bn_bwd_apply")
     if direct:
         for p in (gamma, beta):
             cb = getattr(p, "_pda_grad_ready", None)
@@ -271,7 +304,7 @@ class _BatchNormActFn(torch.autograd.Function):
     """out = relu(bn(y) + residual) on the GPU kernels (stand-alone, not fused with a conv)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, relu: bool, st: BNState):
+    def forward(ctx, y, gamma, beta, residual, relu, st: BNState):
         y = y.contiguous()
         C = y.shape[-1]
         M = y.numel() // C
@@ -301,7 +334,7 @@ class _BatchNormActFn(torch.autograd.Function):
         dout = dout.contiguous()
         if not ctx.train:  # eval-mode BN is an affine map
             out, scale, y, mean, invstd = ctx.saved_tensors
-            g = dout if out is None else dout * (out > 0).to(dout.dtype)
+            g = dout if out is None else dout * relu_mask(out, ctx.relu).to(dout.dtype)
             dg = db = None
             if y is not None:
                 dg, db = eval_affine_grads(g, y, mean, invstd)
@@ -335,7 +368,8 @@ def batch_norm_act_ref(y, gamma, beta, residual, relu, st: BNState):
     if residual is not None:
         o = o + residual
     if relu:
-        o = torch.relu(o)
+        cap = relu_cap(relu)
+        o = torch.relu(o) if cap is None else torch.clamp(o, 0.0, cap)
     return o.contiguous()
 
 
@@ -363,7 +397,7 @@ def _sync_bn_ref(x, gamma, beta, st: BNState, mom):
     return o.to(x.dtype)
 
 
-def batch_norm_act(y, gamma, beta, residual, relu: bool, st: BNState):
+def batch_norm_act(y, gamma, beta, residual, relu, st: BNState):
     if not y.is_cuda or y.shape[-1] % (16 // y.element_size()) != 0:
         # CPU, or a channel count that does not fill 16-byte vectors (58, 122 in ShuffleNetV2): stock math
         return batch_norm_act_ref(y, gamma, beta, residual, relu, st)

@@ -931,6 +931,90 @@ def test_linear_runs_on_the_conv_gemm_kernels(dtype):
     assert rel_err(lin(x), F.linear(x, lin.weight, lin.bias)) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_with_clipped_relu(dtype, training):
+    """BatchNorm + ReLU6 in the BatchNorm passes (``relu=6.0``): forward clip and backward mask (nothing passes at
+    or above the cap) against stock fp32 math, stand-alone and fused behind a conv, with and without a residual;
+    gamma / beta chosen so that a good share of the values lands on either side of both kinks."""
+    from pytorch_distributed_amd import ops
+    from pytorch_distributed_amd.ops import norm as Nm
+    torch.manual_seed(71)
+    N, H, W, Cc = 6, 9, 9, 32
+    tol = 2e-4 if dtype == torch.float32 else 1e-2
+
+    def same(a, b, what):
+        """fp32: every element.  fp16: an element whose rounded value sits on a kink may take the other side of it,
+        so all but a handful of elements, and the direction of the whole tensor."""
+        a, b = a.float(), b.float()
+        if dtype == torch.float32:
+            assert rel_err(a, b) < tol, what
+        elif a.numel() < 1000:   # per-channel sums: a flipped element moves one of them a little
+            assert rel_err(a, b) < 8e-2 and _cos(a, b) > 0.999, (what, rel_err(a, b), _cos(a, b))
+        else:
+            far = ((a - b).abs() > 3e-2 * b.abs().max()).float().mean().item()
+            assert far < 5e-3 and _cos(a, b) > 0.999, (what, far, _cos(a, b))
+
+    def state():
+        return Nm.BNState(1e-5, 0.1, training, torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV),
+                          torch.zeros((), dtype=torch.long, device=DEV))
+
+    def ref(y, gamma, beta, res):
+        yf = y.float().permute(0, 3, 1, 2)
+        o = F.batch_norm(yf, torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), gamma, beta, training, 0.1, 1e-5)
+        o = o.permute(0, 2, 3, 1)
+        if res is not None:
+            o = o + res.float()
+        return torch.clamp(o, 0.0, 6.0)
+
+    for with_res in (False, True):
+        y = torch.randn(N, H, W, Cc, device=DEV).to(dtype).requires_grad_(True)
+        res = torch.randn(N, H, W, Cc, device=DEV).to(dtype).requires_grad_(True) if with_res else None
+        gamma = (2.5 + torch.rand(Cc, device=DEV)).requires_grad_(True)
+        beta = (2.0 + torch.rand(Cc, device=DEV)).requires_grad_(True)
+        g = torch.randn(N, H, W, Cc, device=DEV).to(dtype)
+        out = ops.batch_norm_act(y, gamma, beta, res, 6.0, state())
+        share_hi = (out.float() >= 6.0).float().mean().item()
+        share_lo = (out.float() <= 0.0).float().mean().item()
+        assert 0.05 < share_hi < 0.6 and 0.05 < share_lo < 0.6, (share_hi, share_lo)
+        out.backward(g)
+        y2 = y.detach().clone().requires_grad_(True)
+        r2 = res.detach().clone().requires_grad_(True) if with_res else None
+        g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        o2 = ref(y2, g2, b2, r2)
+        o2.backward(g.float())
+        assert rel_err(out.float(), o2) < tol, (with_res, "out")
+        same(y.grad, y2.grad, (with_res, "dy"))
+        same(gamma.grad, g2.grad, (with_res, "dgamma"))
+        same(beta.grad, b2.grad, (with_res, "dbeta"))
+        if with_res:
+            same(res.grad, r2.grad, "dres")
+
+    # fused behind a conv (the MobileNetV2 expand layers): conv -> BatchNorm -> ReLU6
+    x = torch.randn(N, H, W, 32, device=DEV).to(dtype).requires_grad_(True)
+    w = C.make_weight(Cc, 32, 1, 1, device=DEV)
+    w.data.normal_(0, 0.2)
+    w.requires_grad_(True)
+    gamma = (2.5 + torch.rand(Cc, device=DEV)).requires_grad_(True)
+    beta = (2.0 + torch.rand(Cc, device=DEV)).requires_grad_(True)
+    g = torch.randn(N, H, W, Cc, device=DEV).to(dtype)
+    out = ops.conv_bn_act(x, w, gamma, beta, None, (1, 1), (0, 0), 6.0, state(), C.WeightCache())
+    out.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = w.detach().to(dtype).float().requires_grad_(True)
+    g2, b2 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    yc = F.conv2d(x2.float().permute(0, 3, 1, 2), w2).permute(0, 2, 3, 1)
+    if dtype != torch.float32:
+        yc = yc + (yc.to(dtype).float() - yc).detach()   # the kernel rounds the conv output before the BatchNorm
+    o2 = ref(yc, g2, b2, None)
+    o2.backward(g.float())
+    assert rel_err(out.float(), o2) < tol * 2, "fused out"
+    same(x.grad, x2.grad, "fused dx")
+    same(w.grad.permute(0, 2, 3, 1), w2.grad.permute(0, 2, 3, 1), "fused dw")
+    same(gamma.grad, g2.grad, "fused dgamma")
+    same(beta.grad, b2.grad, "fused dbeta")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 def test_gemm_split_k(dtype):
     """x @ w^T with the reduction split over workgroups (the forward of a Linear layer on a small batch) vs an
