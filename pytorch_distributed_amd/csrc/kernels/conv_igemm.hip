@@ -1013,8 +1013,14 @@ igemm_kernel(ConvArgs a) {
           v1 += gred[e * GS + w * VPR + cvx];
           v2 += gred[(EPC + e) * GS + w * VPR + cvx];
         }
-        a.psum[(long long)prow * a.Co + n0 + t] = v1;
-        a.psq[(long long)prow * a.Co + n0 + t] = v2;
+        if (a.stat_slots > 0) {  // few pre-zeroed rows shared by all tiles (see the statistics write-out below)
+          const long long o = (long long)(prow % a.stat_slots) * a.Co + n0 + t;
+          atomicAdd(a.psum + o, v1);
+          atomicAdd(a.psq + o, v2);
+        } else {
+          a.psum[(long long)prow * a.Co + n0 + t] = v1;
+          a.psq[(long long)prow * a.Co + n0 + t] = v2;
+        }
       }
       PDA_STAMP(4);
       return;
@@ -1659,7 +1665,7 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
   a.M = N * Ho * Wo; a.relu = relu;
   a.Ha = a.Wb = 0;
   if (a.M <= 0 || Co <= 0) return 0;
-  if (bnc != nullptr && (!dgrad || stat_slots > 0)) return -7;
+  if (bnc != nullptr && !dgrad) return -7;
   if (dgrad && (a.sh_log2 < 0 || a.sw_log2 < 0)) return -3;
   if ((long long)N * Ho * Wo > 0x7fffffffLL) return -4;
   {

@@ -197,7 +197,8 @@ def gemm_splitk(x: torch.Tensor, w: torch.Tensor, ksplit: int, cfg: int = 1) -> 
 def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], stride, pad,
               res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None,
               bn_input: Optional[torch.Tensor] = None, bn_scale: Optional[torch.Tensor] = None,
-              bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False, mask_bits: bool = False):
+              bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False, mask_bits: bool = False,
+              sums_buf: Optional[torch.Tensor] = None):
     """dx[N,Hi,Wi,C] from dy[N,Ho,Wo,K]; w_crsk is the [C,R,S,K] transposed weight.
 
     ``res`` ([N,Hi,Wi,C]) is added in the epilogue; ``mask`` ([N,Hi,Wi,C], the forward input when that
@@ -209,7 +210,9 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     input.  With ``bn_scale``/``bn_shift`` (fp32 [C]) that layer's ReLU mask ``bn_input*scale+shift > 0``
     is applied to dx; with ``bn_sums`` the call returns ``(dx, sums)``, ``sums`` = fp32 ``[2, rows, C]``
     per-tile partial sums of dx and of dx*bn_input - the two reductions that BatchNorm's backward
-    needs, taken while the gradient tile is still on chip."""
+    needs, taken while the gradient tile is still on chip.  ``sums_buf`` (fp32 ``[2, slots, C]``, all zeros on
+    entry): when the launch has more tiles than ``slots`` the sums are accumulated into it with float atomics and
+    it is returned as ``sums`` - whoever consumes them zeroes it again (``norm.backward(presums_clear=True)``)."""
     l = _lib.lib()
     N, Ho, Wo, K = dy.shape
     C, R, S = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[2]
@@ -230,16 +233,21 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
                                            or mask.numel() != dx.numel() * dx.element_size() // 16):
         raise ValueError("dgrad_gpu: mask_bits wants one contiguous uint8 per 16 bytes of dx")
     sums = None
+    slots = 0
     if bn_sums:
         if bn_input is None:
             raise ValueError("dgrad_gpu: bn_sums needs bn_input")
         rows = l.pda_conv_dgrad_stat_rows(N, Hi, Wi, C, stride[0], stride[1], cfg)
-        sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
+        if (sums_buf is not None and rows > sums_buf.shape[1] and sums_buf.shape[2] == C and sums_buf.is_contiguous()
+                and sums_buf.dtype == torch.float32 and not backends.deterministic):
+            sums, slots = sums_buf, sums_buf.shape[1]
+        else:
+            sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
     entry = l.pda_conv_igemm_maskbits if (mask_bits and mask is not None) else l.pda_conv_igemm
     rc = entry(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
                           _lib.ptr(mask), _lib.ptr(bn_input), _lib.ptr(bn_scale), _lib.ptr(bn_shift),
                           sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
-                          Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, 0,
+                          Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, slots,
                           _lib.stream())
     if rc == -8:
         # 16-bit dX whose channel count is not a multiple of 8: the epilogue extras only exist in the

@@ -29,6 +29,11 @@ from . import _lib, conv as C, norm as Nm, pool as P, streams
 # ResNet-50 step is fastest with every layer fused (threshold sweep in profiles/bench_1gpu_summary.txt),
 # hence the default 0.
 _SUMS_MIN_K = int(os.environ.get("PDA_FUSE_BN_SUMS_MIN_K", "0"))
+# opt-in: the consumer's dgrad epilogue accumulates the producer's BatchNorm-backward sums into 64 shared rows (float
+# atomics) instead of writing one row per tile for a compression launch to reduce afterwards.  47 launches fewer per
+# ResNet-50 step, but no faster (33.37 / 33.17 ms against 33.35 / 33.07: the small launches already hide under the
+# side stream's weight gradients) and the atomics make the sums' rounding vary from run to run, so it stays off.
+_SUMS_SLOTS = os.environ.get("PDA_BN_SUMS_SLOTS", "0") == "1"
 
 
 # Inference (no_grad + eval): BatchNorm's running-statistics affine is folded into the cached low-precision
@@ -87,10 +92,10 @@ class BNBackwardLink:
     the consumer's epilogue reads those instead of the activation itself.  Only a producer with a ReLU, no residual and batch statistics defers, and only for 16-bit
     activations; a consumer that cannot fuse materialises the activation itself (``materialize_deferred``)."""
 
-    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine", "maskbits")
+    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine", "maskbits", "sums_buf")
 
     def __init__(self, defer: bool = False):
-        self.y = self.scale = self.shift = self.sums = self.xaffine = self.maskbits = None
+        self.y = self.scale = self.shift = self.sums = self.xaffine = self.maskbits = self.sums_buf = None
         self.relu = True
         self.remask = False
         self.defer = defer
@@ -176,6 +181,9 @@ class _ConvBnActFn(torch.autograd.Function):
                 out_link.scale, out_link.shift = scale, shift
             out_link.y = y if train_stats else None
             out_link.sums = None
+            # where the consumer's dgrad epilogue may accumulate this layer's backward reductions: this layer's own
+            # zero-on-entry statistics rows (its backward reads and clears them)
+            out_link.sums_buf = cache.stats_buffer(K, x.device) if train_stats else None
         mask_src = out if (relu and not ctx.premasked and (residual is not None or not train_stats)) else None
         ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd,
                               scale, shift, gamma)
@@ -192,15 +200,17 @@ class _ConvBnActFn(torch.autograd.Function):
         dout = dout.contiguous()
         K, Cin, R, S = weight.shape
         presums = None
+        presums_clear = False
         if ctx.out_link is not None:
             presums, ctx.out_link.sums = ctx.out_link.sums, None
+            presums_clear = presums is not None and presums is ctx.out_link.sums_buf
             ctx.out_link.y = None
         if train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)
             dy, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False,
                                         False, group, ctx.beta, cache.stats_buffer(K, dout.device),
-                                        presums=presums)
+                                        presums=presums, presums_clear=presums_clear)
             dres = dout if has_res else None
         elif train_stats:
             dy, dres, dg, db = Nm.backward(dout, y, mask_src, mean, invstd, scale, shift, gamma, count, relu,
@@ -249,7 +259,8 @@ class _ConvBnActFn(torch.autograd.Function):
                 mk, mkbits = link.maskbits, True
             r = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
                             res=dalias, mask=mk, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
-                            bn_sums=bn_in is not None, mask_bits=mkbits)
+                            bn_sums=bn_in is not None, mask_bits=mkbits,
+                            sums_buf=link.sums_buf if (bn_in is not None and _SUMS_SLOTS) else None)
             if r is None:
                 if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
                     # pointwise conv with a filter count the dgrad kernel does not step through (16, 24 in

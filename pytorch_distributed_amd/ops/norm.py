@@ -223,11 +223,12 @@ def _vec_sink(param):
 
 
 def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu, want_dres: bool,
-             group=None, beta=None, scratch=None, presums=None):
+             group=None, beta=None, scratch=None, presums=None, presums_clear: bool = False):
     """-> dy, dres (or None), dgamma, dbeta.
 
     ``presums`` (fp32 ``[2, rows, C]``: partial sums of ``dout`` and of ``dout*y``, as returned by
-    ``conv.dgrad_gpu(..., bn_sums=True)``) replaces this function's own reduction pass over dout and y.
+    ``conv.dgrad_gpu(..., bn_sums=True)``) replaces this function's own reduction pass over dout and y;
+    ``presums_clear``: they sit in a persistent accumulation buffer that has to be all zeros again afterwards.
 
     When both affine parameters opted into direct gradient accumulation, their gradients are added
     to ``.grad`` by the finalize kernel and ``None`` is returned for them.  ``scratch`` (all-zero fp32
@@ -270,7 +271,8 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                                      dgb[1].data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                                      shift.data_ptr(), _lib.ptr(gamma), float(count),
                                      0 if sync else coef.data_ptr(), sink_g.data_ptr() if direct else 0,
-                                     sink_b.data_ptr() if direct else 0, int(slots > 0), int(presums is not None),
+                                     sink_b.data_ptr() if direct else 0,
+                                     int(slots > 0 or (presums is not None and presums_clear)), int(presums is not None),
                                      _lib.stream()),
                "pda_bn_bwd_finalize")
     if sync:

@@ -632,6 +632,35 @@ def test_dgrad_bn_sums_epilogue(dtype, stride, cfg, remask):
     assert rel_err(sums[1].double().sum(0), (d * c.double().view(-1, Cin)).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_dgrad_bn_sums_into_slot_rows(dtype, stride):
+    """More tiles than accumulation rows: the epilogue adds the BatchNorm-backward sums into the caller's 64 zeroed
+    rows (float atomics) and hands that buffer back; with few tiles it leaves the buffer alone."""
+    torch.manual_seed(29)
+    N, H, W, Cin, K = 12, 28, 28, 128, 64
+    w = (torch.randn(K, 3, 3, Cin, device=DEV) / 24).to(dtype).permute(0, 3, 1, 2)
+    Ho = (H + 2 - 3) // stride + 1
+    dy = torch.randn(N, Ho, Ho, K, device=DEV).to(dtype)
+    c = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    sc, sf = torch.randn(Cin, device=DEV), torch.randn(Cin, device=DEV) * 0.3
+    wt = C.krsc_to_crsk(C.krsc(w), dtype)
+    buf = torch.zeros(2, 64, Cin, device=DEV)
+    dx, sums = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), bn_input=c, bn_scale=sc, bn_shift=sf,
+                           bn_sums=True, sums_buf=buf)
+    assert sums is buf
+    dx2, rows = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), bn_input=c, bn_scale=sc, bn_shift=sf,
+                            bn_sums=True)
+    assert torch.equal(dx, dx2) and rows.shape[1] > 64
+    d = dx.double().view(-1, Cin)
+    assert rel_err(sums[0].double().sum(0), d.sum(0)) < 1e-5
+    assert rel_err(sums[1].double().sum(0), (d * c.double().view(-1, Cin)).sum(0)) < 1e-5
+    small = torch.zeros(2, 64, Cin, device=DEV)
+    _, s3 = C.dgrad_gpu(dy[:1], wt, (H, W), (stride, stride), (1, 1), bn_input=c[:1], bn_scale=sc, bn_shift=sf,
+                        bn_sums=True, sums_buf=small)
+    assert s3 is not small and not small.any()
+
+
 @pytest.mark.parametrize("n,c", [(5000, 96), (1024, 64), (40000, 256), (700, 64)])
 def test_compress_partials(n, c):
     from pytorch_distributed_amd.ops import norm as Nm
