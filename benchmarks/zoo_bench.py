@@ -5,6 +5,7 @@ forward + loss + backward + optimiser step.  One line per architecture (also app
     python benchmarks/zoo_bench.py --batch 128 --archs resnet50,vgg16_bn,densenet121 --out gpurun_out/zoo.txt
 """
 import argparse
+import gc
 import os
 import sys
 import time
@@ -70,6 +71,7 @@ def main():
         if a.out:
             with open(a.out, "a") as f:
                 f.write(line + "\n")
+        gc.collect()   # the previous model (autograd graphs hold cycles) must be gone, not just unreferenced
         torch.cuda.empty_cache()
 
 
