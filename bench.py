@@ -462,6 +462,8 @@ def worker(args) -> int:
     vs_stock = stock_ips = None
     if args.compare_stock and args.engine == "native" and not on_cpu:
         del model, step
+        import gc
+        gc.collect()               # the native model must be gone, not merely unreferenced, before the comparator runs
         torch.cuda.empty_cache()
         try:
             _, sstep = build_stock(True)
