@@ -62,6 +62,8 @@ def main():
     p.add_argument("--warmup", type=int, default=6)
     p.add_argument("--out", default="")
     p.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
+    p.add_argument("--keep-garbage", action="store_true",
+                   help="diagnostic: do not collect the previous model before the next one is measured")
     a = p.parse_args()
     backends.benchmark = True
     for arch in a.archs.split(","):
@@ -71,7 +73,8 @@ def main():
         if a.out:
             with open(a.out, "a") as f:
                 f.write(line + "\n")
-        gc.collect()   # the previous model (autograd graphs hold cycles) must be gone, not just unreferenced
+        if not a.keep_garbage:
+            gc.collect()   # the previous model (autograd graphs hold cycles) must be gone, not just unreferenced
         torch.cuda.empty_cache()
 
 

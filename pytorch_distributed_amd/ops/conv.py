@@ -377,7 +377,8 @@ class WeightCache:
     only when the parameter has changed (torch version counter or our optimizer's
     generation counter)."""
 
-    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "stats", "key_fold", "fold", "__weakref__")
+    __slots__ = ("key_lp", "lp", "key_t", "t", "pinned_lp", "t_weight", "stats", "key_fold", "fold", "used_gen",
+                 "t_layout", "__weakref__")
 
     STAT_SLOTS = 64
 
@@ -403,6 +404,8 @@ class WeightCache:
         self.key_t = None
         self.t = None
         self.t_weight = None   # weakref to the parameter the transpose in ``t`` belongs to
+        self.used_gen = 0      # optimizer generation in which the transpose was last asked for
+        self.t_layout = None   # (shape, strides) of the parameter when ``t`` was built from its KRSC memory
 
     @staticmethod
     def _key(weight: torch.Tensor, dtype) -> tuple:
@@ -442,6 +445,7 @@ class WeightCache:
         return self.fold
 
     def transposed(self, weight: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        self.used_gen = _PARAM_GENERATION
         key = self._key(weight, dtype)
         if self.key_t != key:
             K, C, R, S = weight.shape
@@ -452,9 +456,12 @@ class WeightCache:
                 _refresh_transposes(dtype, weight.device)
                 if self.key_t == key:
                     return self.t
-            self.t = krsc_to_crsk(krsc(weight.detach()), dtype)
+            wk = krsc(weight.detach())
+            self.t = krsc_to_crsk(wk, dtype)
             self.key_t = key
             self.t_weight = weakref.ref(weight)
+            # the batched refresh reads the parameter's memory as KRSC: only while it keeps this exact layout
+            self.t_layout = (tuple(weight.shape), tuple(weight.stride())) if wk.data_ptr() == weight.data_ptr() else None
             _T_CACHES.add(self)
         return self.t
 
@@ -467,12 +474,14 @@ def _refresh_transposes(dtype: torch.dtype, device) -> None:
     """Recompute, in one launch, every registered CRSK transpose of ``dtype`` on ``device`` that is stale."""
     todo = []
     for c in _T_CACHES:
+        if c.used_gen + 8 < _PARAM_GENERATION:
+            continue  # not asked for in the last few optimizer steps (a model that is no longer training): it
+                      # refreshes on its own when it is used again, instead of costing every step of the others
         w = c.t_weight() if c.t_weight is not None else None
         if w is None or c.t is None or c.t.dtype != dtype or c.t.device != device or w.device != device:
             continue
         key = WeightCache._key(w, dtype)
-        if c.key_t != key and c.t.shape == (w.shape[1], w.shape[2], w.shape[3], w.shape[0]) \
-                and krsc(w.detach()).is_contiguous():
+        if c.key_t != key and c.t_layout == (tuple(w.shape), tuple(w.stride())):
             todo.append((c, w, key))
     if not todo:
         return
