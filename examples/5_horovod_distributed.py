@@ -28,7 +28,13 @@ def main():
     model = engine.make_model(args, device)
     per_rank = int(args.batch_size / hvd.size())
     hvd.broadcast_parameters(model.state_dict(), root_rank=0)
-    optimizer = engine.make_optimizer(args, model, fused=False)
+    # fp32 (the upstream script): the stock optimizer under the Horovod wrapper.  --precision fp16 / bf16: this
+    # package's fused optimizer, whose update kernel unscales and checks for overflow AFTER the wrapper has
+    # synchronised the (still scaled) gradients - the order the Horovod + apex recipe asks for
+    mixed = args.precision != "fp32"
+    optimizer = engine.make_optimizer(args, model, fused=mixed)
+    if mixed:
+        model, optimizer = engine.setup_amp(args, model, optimizer)
     hvd.broadcast_optimizer_state(optimizer, root_rank=0)
     optimizer = hvd.DistributedOptimizer(optimizer, named_parameters=model.named_parameters(),
                                          compression=hvd.Compression.fp16)

@@ -47,7 +47,8 @@ class _Reducing:
         self._synchronized = False
         self._should_synchronize = True
         self._reduced_params = [p for p in params if p.requires_grad]
-        self._hooks = [p.register_post_accumulate_grad_hook(self._hvd_hook) for p in self._reduced_params]
+        self._direct_fired = set()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hvd_autograd_hook) for p in self._reduced_params]
         # This package's fused conv / BatchNorm ops accumulate weight gradients straight into an existing
         # ``.grad`` (no AccumulateGrad node, so no autograd hook): they announce such a gradient through
         # ``_pda_grad_ready`` instead, which keeps the reduction overlapped with the rest of backward.
@@ -70,7 +71,16 @@ class _Reducing:
                     self._hvd_hook(p)
             else:
                 self._hvd_hook(p)
+            self._direct_fired.add(p)
         return ready
+
+    def _hvd_autograd_hook(self, p):
+        # autograd runs a parameter's AccumulateGrad node - and with it this hook - even when the op returned no
+        # gradient for it because it had already accumulated into ``.grad`` and announced that itself
+        if p in self._direct_fired:
+            self._direct_fired.discard(p)
+            return
+        self._hvd_hook(p)
 
     # -- gradient hooks -----------------------------------------------------------------------
     def _hvd_launch(self, p):
@@ -87,8 +97,9 @@ class _Reducing:
 
     def _hvd_hook(self, p):
         if self._handles.get(p) is not None:
-            raise AssertionError("a gradient was produced again before step()/synchronize() consumed the previous "
-                                 "reduction: raise backward_passes_per_step to accumulate locally")
+            raise AssertionError(f"the gradient of {self._name_of.get(p, '<unnamed>')!r} was produced again before "
+                                 "step()/synchronize() consumed the previous reduction: raise "
+                                 "backward_passes_per_step to accumulate locally")
         self._passes_left[p] -= 1
         self._handles[p] = self._hvd_launch(p) if self._passes_left[p] <= 0 else None
 
@@ -103,6 +114,7 @@ class _Reducing:
                 M.synchronize(h)
                 self._passes_left[p] = self.backward_passes_per_step
         self._handles.clear()
+        self._direct_fired.clear()
         self._synchronized = True
 
     @contextlib.contextmanager

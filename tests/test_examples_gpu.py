@@ -55,6 +55,16 @@ def test_style5_horovod_one_gpu(tmp_path):
     assert out.count(" * Acc@1") == 2
 
 
+def test_style5_horovod_mixed_precision_fused_optimizer(tmp_path):
+    """--precision fp16: the Horovod wrapper around this package's fused optimizer under amp O2.  The fused conv /
+    BatchNorm / Linear ops accumulate their gradients in place and announce them themselves, and autograd still
+    runs each parameter's post-accumulate hook afterwards: every gradient must be reduced exactly once per step."""
+    out = run(LAUNCH + ["-np", "1", "-H", "localhost:1", "--master_port", str(free_port()),
+                        os.path.join(EX, "5_horovod_distributed.py")] + COMMON +
+              ["--precision", "fp16", "--opt-level", "O2"], tmp_path)
+    assert out.count(" * Acc@1") == 2
+
+
 @pytest.mark.parametrize("arch,extra", [("mobilenet_v2", ["--graph"]), ("densenet121", []), ("shufflenet_v2_x1_0", []),
                                         ("resnext50_32x4d", ["--graph"]), ("googlenet", [])])
 def test_other_arch_amp_ddp_one_gpu(tmp_path, arch, extra):
