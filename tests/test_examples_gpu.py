@@ -65,6 +65,13 @@ def test_style5_horovod_mixed_precision_fused_optimizer(tmp_path):
     assert out.count(" * Acc@1") == 2
 
 
+def test_hvd_optimizer_combinations_one_gpu(tmp_path):
+    """hvd.DistributedOptimizer around the fused and the stock optimizer, with and without mixed precision, fp16
+    compression and local accumulation (backward_passes_per_step): each trains (tests/workers/hvd_combos_gpu.py)."""
+    out = run([sys.executable, os.path.join(ROOT, "tests", "workers", "hvd_combos_gpu.py")], tmp_path)
+    assert out.count(" ok ") == 7 and "FAIL" not in out, out
+
+
 @pytest.mark.parametrize("arch,extra", [("mobilenet_v2", ["--graph"]), ("densenet121", []), ("shufflenet_v2_x1_0", []),
                                         ("resnext50_32x4d", ["--graph"]), ("googlenet", [])])
 def test_other_arch_amp_ddp_one_gpu(tmp_path, arch, extra):
