@@ -72,6 +72,13 @@ def test_hvd_optimizer_combinations_one_gpu(tmp_path):
     assert out.count(" ok ") == 7 and "FAIL" not in out, out
 
 
+def test_ddp_combinations_one_gpu(tmp_path):
+    """DistributedDataParallel (one rank, own RCCL communicator) with the fused and the stock optimizer, O0 / O1 / O2,
+    no_sync() accumulation, the apex-flavoured wrapper and SyncBatchNorm: each trains (tests/workers/ddp_combos_gpu.py)."""
+    out = run([sys.executable, os.path.join(ROOT, "tests", "workers", "ddp_combos_gpu.py")], tmp_path)
+    assert out.count(" ok ") == 10 and "FAIL" not in out, out
+
+
 @pytest.mark.parametrize("arch,extra", [("mobilenet_v2", ["--graph"]), ("densenet121", []), ("shufflenet_v2_x1_0", []),
                                         ("resnext50_32x4d", ["--graph"]), ("googlenet", [])])
 def test_other_arch_amp_ddp_one_gpu(tmp_path, arch, extra):
