@@ -94,3 +94,38 @@ def test_other_arch_dataparallel_one_gpu(tmp_path):
     common = [a if a != "resnet18" else "squeezenet1_1" for a in COMMON]
     out = run([sys.executable, os.path.join(EX, "1_dataparallel.py")] + common, tmp_path)
     assert out.count(" * Acc@1") == 2
+
+
+def test_image_directory_pipeline_on_the_gpu(tmp_path):
+    """--dataset imagenet --data DIR on the device path: PNG files -> uint8 batches -> normalisation inside the stem
+    kernel.  The uint8 route gives the model output of the ToTensor + Normalize route, and the launch-style example
+    trains from the directory (ResNet-50 stem: fused normalise + conv + BatchNorm + ReLU + pool)."""
+    PIL = pytest.importorskip("PIL")
+    import numpy as np
+    import torch
+    from PIL import Image
+    from pytorch_distributed_amd import data as D, models
+    rng = np.random.RandomState(0)
+    root = tmp_path / "imgs"
+    for split in ("train", "val"):
+        for cls in ("n01_cat", "n02_dog"):
+            d = root / split / cls
+            d.mkdir(parents=True)
+            for i, (w, h) in enumerate(((300, 400), (500, 333), (224, 224), (256, 256))):
+                Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(d / f"img_{i}.png")
+    dev = torch.device("cuda", 0)
+    vu, vf = D.imagenet(str(root), False), D.imagenet(str(root), False, uint8=False)
+    xu = torch.stack([vu[i][0] for i in range(4)]).to(dev)
+    xf = torch.stack([vf[i][0] for i in range(4)]).to(dev)
+    assert xu.dtype == torch.uint8
+    torch.manual_seed(0)
+    m = models.get_model("resnet50", num_classes=8).to(dev).eval()
+    with torch.no_grad():
+        ref = m(xf)
+        m.set_input_normalization(D.IMAGENET_MEAN, D.IMAGENET_STD, 1.0 / 255.0)
+        out = m(xu)
+    assert torch.allclose(out.float(), ref.float(), atol=2e-3, rtol=2e-3), (out - ref).abs().max().item()
+    txt = run([sys.executable, os.path.join(EX, "6_distributed_slurm.py"), "--dataset", "imagenet", "--data", str(root),
+               "-a", "resnet50", "-b", "4", "--epochs", "1", "--num-classes", "2", "-j", "2", "-p", "1",
+               "--precision", "fp16", "--opt-level", "O2"], tmp_path)
+    assert txt.count(" * Acc@1") == 1 and "Epoch: [0][1/2]" in txt
