@@ -1,0 +1,58 @@
+"""hvd.DistributedOptimizer around the fused optimizer under amp O2, 2+ ranks sharing GPU 0 (engine collectives
+through the peer-memory backend): a ResNet-18 whose fused conv / BatchNorm / Linear ops accumulate their gradients in
+place and announce them themselves, some from the backward side stream.  Every gradient must be reduced exactly once
+per step: after three steps the ranks (different data, different initial weights before the broadcast) hold identical
+parameters and the loss has fallen.
+argv: rank world port"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(HOROVOD_RANK=str(rank), HOROVOD_SIZE=str(world), HOROVOD_LOCAL_RANK=str(rank),
+                  HOROVOD_LOCAL_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                  PDA_HVD_NO_CUDA="1", PDA_HVD_DEVICE_COMM="p2p", PDA_HVD_P2P_DEVICE="0")
+import torch
+
+import pytorch_distributed_amd.hvd as hvd
+from pytorch_distributed_amd import amp, models, ops
+from pytorch_distributed_amd.optim import FusedSGD
+
+
+def main():
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    hvd.init()
+    assert hvd.size() == world and hvd.rank() == rank
+    torch.manual_seed(200 + rank)
+    net = models.get_model("resnet18", num_classes=16).to(dev)
+    hvd.broadcast_parameters(net.state_dict(), root_rank=0)
+    opt = FusedSGD(net.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    net, opt = amp.initialize(net, opt, opt_level="O2", verbosity=0, loss_scale=128.0)
+    hvd.broadcast_optimizer_state(opt, root_rank=0)
+    opt = hvd.DistributedOptimizer(opt, named_parameters=net.named_parameters(), compression=hvd.Compression.fp16)
+    torch.manual_seed(300 + rank)          # every rank its own shard
+    x = torch.randn(16, 3, 64, 64, device=dev)
+    t = torch.randint(0, 16, (16,), device=dev)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = ops.cross_entropy(net(x), t)
+        with amp.scale_loss(loss, opt) as scaled:
+            scaled.backward()
+        opt.step()
+        losses.append(loss.item())
+    flat = torch.cat([p.detach().float().flatten() for p in net.parameters()])
+    probe = torch.stack([flat.sum(), flat.abs().sum(), flat[::97].double().pow(2).sum().float()])
+    allp = hvd.allgather(probe.view(1, 3), name="probe")
+    same = bool((allp - allp[0:1]).abs().max() == 0)
+    finite = bool(torch.isfinite(flat).all())
+    ok = same and finite and losses[-1] < losses[0] and all(l == l for l in losses)
+    print(f"rank {rank}: {'OK' if ok else 'FAILED'} ranks agree {same}, finite {finite}, loss {losses[0]:.3f} -> "
+          f"{losses[-1]:.3f}", flush=True)
+    hvd.shutdown()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
