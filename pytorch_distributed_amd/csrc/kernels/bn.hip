@@ -16,10 +16,38 @@
 // (and the masked gradient for the residual branch).
 #include "common.h"
 
+// VB = bytes one lane moves per access in the element-wise and column-reduction kernels below: 16 for every channel
+// count that fills whole 16-byte vectors (the instantiations all ResNet-style widths use), 4 for the others with an
+// even 16-bit (or any fp32) count - the 58 / 116 channels per branch of ShuffleNetV2.
+template <typename T, int VB> using VecB = VecN<T, VB / (int)sizeof(T)>;
+template <typename T, int VB>
+__device__ __forceinline__ VecB<T, VB> ldv(const T* p) {
+  VecB<T, VB> r;
+  if constexpr (VB == 16) *reinterpret_cast<u32x4*>(&r) = *reinterpret_cast<const u32x4*>(p);
+  else *reinterpret_cast<unsigned*>(&r) = *reinterpret_cast<const unsigned*>(p);
+  return r;
+}
+template <typename T, int VB>
+__device__ __forceinline__ VecB<T, VB> ldv_stream(const T* p) {
+  VecB<T, VB> r;
+  if constexpr (VB == 16) *reinterpret_cast<u32x4*>(&r) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else *reinterpret_cast<unsigned*>(&r) = *reinterpret_cast<const unsigned*>(p);
+  return r;
+}
+template <typename T, int VB>
+__device__ __forceinline__ void stv_maybe_stream(T* p, const VecB<T, VB>& v, int stream) {
+  if constexpr (VB == 16) {
+    if (stream) __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(&v);
+  } else {
+    *reinterpret_cast<unsigned*>(p) = *reinterpret_cast<const unsigned*>(&v);
+  }
+}
+
 // Column-reduction geometry shared by the reduce kernels: a 256-thread block
 // covers VT = min(C/EPC, 256) channel vectors x RS = 256/VT rows per pass.
-template <typename T> struct ColGeom {
-  static constexpr int EPC = 16 / sizeof(T);
+template <typename T, int VB = 16> struct ColGeom {
+  static constexpr int EPC = VB / sizeof(T);
   int VT, RS, vec, rl;
   __device__ ColGeom(int C, int cblk) {
     const int vpr = C / EPC;
@@ -35,13 +63,13 @@ template <typename T> struct ColGeom {
   }
 };
 
-template <typename T>
+template <typename T, int VB = 16>
 __global__ void __launch_bounds__(256)
 bn_stats_partial_kernel(const T* __restrict__ y, long long M, int C, float* __restrict__ psum,
                         float* __restrict__ psq) {
-  constexpr int EPC = 16 / sizeof(T);
+  constexpr int EPC = VB / sizeof(T);
   __shared__ float red[2][256 * EPC];
-  ColGeom<T> g(C, blockIdx.y);
+  ColGeom<T, VB> g(C, blockIdx.y);
   const int vpr = C / EPC;
   float s[EPC], q[EPC];
 #pragma unroll
@@ -51,7 +79,7 @@ bn_stats_partial_kernel(const T* __restrict__ y, long long M, int C, float* __re
     const long long r0 = blockIdx.x * rows_per_blk;
     const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
     for (long long r = r0 + g.rl; r < r1; r += g.RS) {
-      Vec16<T> v = load16(y + r * C + (long long)g.vec * EPC);
+      VecB<T, VB> v = ldv<T, VB>(y + r * C + (long long)g.vec * EPC);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const float f = ElemTraits<T>::to_f32(v.v[e]);
@@ -262,12 +290,12 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict_
 // Every thread keeps one 16-byte channel vector for the whole grid-stride loop
 // (the stride is a multiple of the vectors per row), so scale/shift live in registers.
 // CAP (compile time): the activation is a ReLU clipped at `cap` (ReLU6); the plain instantiations are unchanged.
-template <typename T, bool CAP = false>
+template <typename T, bool CAP = false, int VB = 16>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                 const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
                 int relu, unsigned char* __restrict__ mask_out, int stream_out, float cap = 0.f) {
-  constexpr int EPC = 16 / sizeof(T);
+  constexpr int EPC = VB / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -276,10 +304,10 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e]; }
   for (; i < nvec; i += stride) {
-    Vec16<T> v = load16_stream(y + i * EPC);
-    Vec16<T> rv;
-    if (res) rv = load16_stream(res + i * EPC);
-    Vec16<T> o;
+    VecB<T, VB> v = ldv_stream<T, VB>(y + i * EPC);
+    VecB<T, VB> rv;
+    if (res) rv = ldv_stream<T, VB>(res + i * EPC);
+    VecB<T, VB> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float f = ElemTraits<T>::to_f32(v.v[e]) * sc[e] + sf[e];
@@ -288,7 +316,7 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
       if (CAP) f = fminf(f, cap);
       o.v[e] = ElemTraits<T>::from_f32(f);
     }
-    store16_maybe_stream(out + i * EPC, o, stream_out);
+    stv_maybe_stream<T, VB>(out + i * EPC, o, stream_out);
     if (mask_out != nullptr) {
       // one byte per 16-byte vector: bit e = element e is positive.  Whoever applies this layer's ReLU
       // backward (the dgrad epilogue of the consuming conv) reads these bits instead of the activation:
@@ -306,15 +334,15 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 // MASK (compile time, so that no load sits behind a run-time branch): 0 = no ReLU, 1 = mask
 // recomputed from y, 2 = mask read from `out`.
 // CAP: the ReLU was clipped at `cap`; values at or above it pass no gradient either.
-template <typename T, int MASK, bool CAP = false>
+template <typename T, int MASK, bool CAP = false, int VB = 16>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                      const float* __restrict__ mean, const float* __restrict__ invstd,
                      const float* __restrict__ scale, const float* __restrict__ shift, long long M, int C,
                      int relu, float* __restrict__ pdg, float* __restrict__ pdb, int slots, float cap = 0.f) {
-  constexpr int EPC = 16 / sizeof(T);
+  constexpr int EPC = VB / sizeof(T);
   __shared__ float red[2][256 * EPC];
-  ColGeom<T> g(C, blockIdx.y);
+  ColGeom<T, VB> g(C, blockIdx.y);
   const int vpr = C / EPC;
   // The loop accumulates sum(g) and sum(g*y) only; sum(g*xhat) = invstd * (sum(g*y) - mean*sum(g)) is
   // formed once per workgroup at the end, which keeps mean/invstd out of the loop's registers
@@ -334,7 +362,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
     const long long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
     const long long r0 = blockIdx.x * rows_per_blk;
     const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
-    auto accum = [&](const Vec16<T>& vd, const Vec16<T>& vy, const Vec16<T>& vo) {
+    auto accum = [&](const VecB<T, VB>& vd, const VecB<T, VB>& vy, const VecB<T, VB>& vo) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         float gd = ElemTraits<T>::to_f32(vd.v[e]);
@@ -355,23 +383,23 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
     long long r = r0 + g.rl;
     // four rows in flight per thread: the loop is latency-bound otherwise
     for (; r + 3 * g.RS < r1; r += 4 * g.RS) {
-      Vec16<T> vd[4], vy[4], vo[4];
+      VecB<T, VB> vd[4], vy[4], vo[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long o = (r + (long long)u * g.RS) * C + (long long)g.vec * EPC;
-        vd[u] = load16(dout + o);
-        vy[u] = load16(y + o);
-        if (need_out) vo[u] = load16(out + o);
+        vd[u] = ldv<T, VB>(dout + o);
+        vy[u] = ldv<T, VB>(y + o);
+        if (need_out) vo[u] = ldv<T, VB>(out + o);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) accum(vd[u], vy[u], vo[u]);
     }
     for (; r < r1; r += g.RS) {
       const long long o = r * C + (long long)g.vec * EPC;
-      Vec16<T> vd = load16(dout + o);
-      Vec16<T> vy = load16(y + o);
-      Vec16<T> vo;
-      if (need_out) vo = load16(out + o);
+      VecB<T, VB> vd = ldv<T, VB>(dout + o);
+      VecB<T, VB> vy = ldv<T, VB>(y + o);
+      VecB<T, VB> vo;
+      if (need_out) vo = ldv<T, VB>(out + o);
       accum(vd, vy, vo);
     }
   }
@@ -422,12 +450,12 @@ bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const 
 // dy = A[c]*g + B[c]*y + K[c]  with the three per-channel coefficients prepared by
 // bn_bwd_coefs_kernel (algebraically gamma*invstd*(g - dbeta/M - xhat*dgamma/M));
 // coef = [5][C] = {A, B, K, scale, shift}, all held in registers (see bn_apply_kernel).
-template <typename T, bool CAP = false>
+template <typename T, bool CAP = false, int VB = 16>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T* __restrict__ out,
                     const float* __restrict__ coef, long long nvec, int C, int relu,
                     T* __restrict__ dy, T* __restrict__ dres, int stream_out, float cap = 0.f) {
-  constexpr int EPC = 16 / sizeof(T);
+  constexpr int EPC = VB / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -442,11 +470,11 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
     sf[e] = coef[4 * C + c0 + e];
   }
   for (; i < nvec; i += stride) {
-    Vec16<T> vd = load16_stream(dout + i * EPC);
-    Vec16<T> vy = load16_stream(y + i * EPC);
-    Vec16<T> vo;
-    if (relu && out) vo = load16(out + i * EPC);
-    Vec16<T> o, og;
+    VecB<T, VB> vd = ldv_stream<T, VB>(dout + i * EPC);
+    VecB<T, VB> vy = ldv_stream<T, VB>(y + i * EPC);
+    VecB<T, VB> vo;
+    if (relu && out) vo = ldv<T, VB>(out + i * EPC);
+    VecB<T, VB> o, og;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float gd = ElemTraits<T>::to_f32(vd.v[e]);
@@ -459,8 +487,8 @@ bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y, const T
       o.v[e] = ElemTraits<T>::from_f32(cA[e] * gd + cB[e] * yv + cK[e]);
       og.v[e] = ElemTraits<T>::from_f32(gd);
     }
-    store16_maybe_stream(dy + i * EPC, o, stream_out);
-    if (dres) store16_maybe_stream(dres + i * EPC, og, stream_out);
+    stv_maybe_stream<T, VB>(dy + i * EPC, o, stream_out);
+    if (dres) stv_maybe_stream<T, VB>(dres + i * EPC, og, stream_out);
   }
 }
 
@@ -513,8 +541,15 @@ __global__ void bn_bwd_coefs_kernel(const float* __restrict__ dg, const float* _
 }
 
 // ------------------------------------------------------------- host side ----
+// bytes per lane access for a channel count (see VB above); 0: not covered (odd 16-bit channel counts)
+static inline int bn_vec_bytes(int C, int es) {
+  if (C % (16 / es) == 0) return 16;
+  return (C * es) % 4 == 0 ? 4 : 0;
+}
+
 static inline int col_blocks_y(int C, int es) {
-  const int vpr = C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  const int vpr = C / ((vb ? vb : 16) / es);
   int vt = vpr < 256 ? vpr : 256;
   int p = 1;
   while (p * 2 <= vt) p *= 2;
@@ -533,9 +568,24 @@ static inline int col_blocks_y(int C, int es) {
 // allocates [n][C].  A block covers RS = 256/VT rows per pass (VT = channel vectors per block), so
 // wide, short tensors (late ResNet stages: M small, C = 2048) still get ~1024 workgroups with at
 // least four passes each instead of a handful of long serial loops.
+// The call sees the element type T and the compile-time access width VB (16 or 4).  (Variadic: the launch macro
+// expands to <<<a, b, c, d>>>, whose commas must not split the argument when it is handed on.)
+#define PDA_DISPATCH_TVB_CASE(TYPE, ...) { typedef TYPE T; __VA_ARGS__; } break;
+#define PDA_DISPATCH_TVB_WIDTH(dtype, ...)               \
+  switch (dtype) {                                       \
+    case PDA_F32: PDA_DISPATCH_TVB_CASE(float, __VA_ARGS__) \
+    case PDA_F16: PDA_DISPATCH_TVB_CASE(f16, __VA_ARGS__)   \
+    case PDA_BF16: PDA_DISPATCH_TVB_CASE(bf16, __VA_ARGS__) \
+    default: return -6;                                  \
+  }
+#define PDA_DISPATCH_TVB(dtype, vb, ...)                                            \
+  if ((vb) == 16) { constexpr int VB = 16; PDA_DISPATCH_TVB_WIDTH(dtype, __VA_ARGS__) } \
+  else { constexpr int VB = 4; PDA_DISPATCH_TVB_WIDTH(dtype, __VA_ARGS__) }
+
 PDA_EXPORT int pda_bn_num_partials(long long M, int C, int dtype) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  const int vpr = C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  const int vpr = C / ((vb ? vb : 16) / es);
   int vt = vpr < 256 ? vpr : 256;
   int p = 1;
   while (p * 2 <= vt) p *= 2;
@@ -549,10 +599,11 @@ PDA_EXPORT int pda_bn_num_partials(long long M, int C, int dtype) {
 PDA_EXPORT int pda_bn_stats_partial(int dtype, const void* y, long long M, int C, float* psum, float* psq,
                                     hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0 || ((uintptr_t)y & 15)) return -1;
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0 || ((uintptr_t)y & (vb - 1))) return -1;
   const int nb = pda_bn_num_partials(M, C, dtype);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_stats_partial_kernel<T>), dim3(nb, col_blocks_y(C, es)), dim3(256),
-                                           0, st, (const T*)y, M, C, psum, psq));
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_stats_partial_kernel<T, VB>), dim3(nb, col_blocks_y(C, es)),
+                                                 dim3(256), 0, st, (const T*)y, M, C, psum, psq));
   return pda_check_launch();
 }
 
@@ -673,13 +724,14 @@ static inline int ew_blocks_chan(long long nvec, int vpr) {
 static int bn_apply_impl(int dtype, const void* y, const void* res, void* out, const float* scale,
                          const float* shift, long long M, int C, int relu, unsigned char* mask_out, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
-  const long long nvec = M * C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0 || (M * C * es) % vb != 0 || (mask_out != nullptr && vb != 16)) return -1;
+  const long long nvec = M * C / (vb / es);
   if (nvec == 0) return 0;
-  const int vpr = C / (16 / es);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
-                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu, mask_out,
-                                           (int)(nvec * 16 >= pda_stream_min_bytes())));
+  const int vpr = C / (vb / es);
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_apply_kernel<T, false, VB>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256),
+                                                 0, st, (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, relu,
+                                                 mask_out, (int)(nvec * vb >= pda_stream_min_bytes())));
   return pda_check_launch();
 }
 
@@ -692,13 +744,14 @@ PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out
 PDA_EXPORT int pda_bn_apply_cap(int dtype, const void* y, const void* res, void* out, const float* scale,
                                 const float* shift, long long M, int C, float cap, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
-  const long long nvec = M * C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0 || (M * C * es) % vb != 0) return -1;
+  const long long nvec = M * C / (vb / es);
   if (nvec == 0) return 0;
-  const int vpr = C / (16 / es);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_kernel<T, true>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0, st,
-                                           (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, 1,
-                                           (unsigned char*)nullptr, (int)(nvec * 16 >= pda_stream_min_bytes()), cap));
+  const int vpr = C / (vb / es);
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_apply_kernel<T, true, VB>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256),
+                                                 0, st, (const T*)y, (const T*)res, (T*)out, scale, shift, nvec, C, 1,
+                                                 (unsigned char*)nullptr, (int)(nvec * vb >= pda_stream_min_bytes()), cap));
   return pda_check_launch();
 }
 
@@ -714,14 +767,15 @@ PDA_EXPORT int pda_bn_bwd_reduce(int dtype, const void* dout, const void* y, con
                                  const float* invstd, const float* scale, const float* shift, long long M, int C,
                                  int relu, float* pdg, float* pdb, int slots, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0) return -1;
   const int nb = pda_bn_num_partials(M, C, dtype);
   const int mask = !relu ? 0 : (out ? 2 : 1);
-#define PDA_BWD_REDUCE(MASK)                                                                                  \
-  PDA_DISPATCH_T(dtype,                                                                                       \
-                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK>), dim3(nb, col_blocks_y(C, es)), dim3(256), \
-                                    0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale,   \
-                                    shift, M, C, relu, pdg, pdb, slots))
+#define PDA_BWD_REDUCE(MASK)                                                                                       \
+  PDA_DISPATCH_TVB(dtype, vb,                                                                                      \
+                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, false, VB>), dim3(nb, col_blocks_y(C, es)),   \
+                                      dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, \
+                                      scale, shift, M, C, relu, pdg, pdb, slots))
   if (mask == 0) { PDA_BWD_REDUCE(0); }
   else if (mask == 1) { PDA_BWD_REDUCE(1); }
   else { PDA_BWD_REDUCE(2); }
@@ -734,13 +788,14 @@ PDA_EXPORT int pda_bn_bwd_reduce_cap(int dtype, const void* dout, const void* y,
                                      const float* invstd, const float* scale, const float* shift, long long M, int C,
                                      float cap, float* pdg, float* pdb, int slots, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0) return -1;
   const int nb = pda_bn_num_partials(M, C, dtype);
-#define PDA_BWD_REDUCE_CAP(MASK)                                                                                     \
-  PDA_DISPATCH_T(dtype,                                                                                              \
-                 hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, true>), dim3(nb, col_blocks_y(C, es)), dim3(256), \
-                                    0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, scale, shift,   \
-                                    M, C, 1, pdg, pdb, slots, cap))
+#define PDA_BWD_REDUCE_CAP(MASK)                                                                                  \
+  PDA_DISPATCH_TVB(dtype, vb,                                                                                     \
+                   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MASK, true, VB>), dim3(nb, col_blocks_y(C, es)),   \
+                                      dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, mean, invstd, \
+                                      scale, shift, M, C, 1, pdg, pdb, slots, cap))
   if (out == nullptr) { PDA_BWD_REDUCE_CAP(1); }
   else { PDA_BWD_REDUCE_CAP(2); }
 #undef PDA_BWD_REDUCE_CAP
@@ -774,13 +829,14 @@ PDA_EXPORT int pda_bn_bwd_coefs(const float* dg, const float* db, int C, const f
 PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, const void* out, const float* coef,
                                 long long M, int C, int relu, void* dy, void* dres, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
-  const long long nvec = M * C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0 || (M * C * es) % vb != 0) return -1;
+  const long long nvec = M * C / (vb / es);
   if (nvec == 0) return 0;
-  const int vpr = C / (16 / es);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
-                                           st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, relu,
-                                           (T*)dy, (T*)dres, (int)(nvec * 16 >= pda_stream_min_bytes())));
+  const int vpr = C / (vb / es);
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, VB>), dim3(ew_blocks_chan(nvec, vpr)),
+                                                 dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec,
+                                                 C, relu, (T*)dy, (T*)dres, (int)(nvec * vb >= pda_stream_min_bytes())));
   return pda_check_launch();
 }
 
@@ -788,12 +844,13 @@ PDA_EXPORT int pda_bn_bwd_apply(int dtype, const void* dout, const void* y, cons
 PDA_EXPORT int pda_bn_bwd_apply_cap(int dtype, const void* dout, const void* y, const void* out, const float* coef,
                                     long long M, int C, float cap, void* dy, void* dres, hipStream_t st) {
   const int es = dtype == PDA_F32 ? 4 : 2;
-  if (C % (16 / es) != 0) return -1;
-  const long long nvec = M * C / (16 / es);
+  const int vb = bn_vec_bytes(C, es);
+  if (vb == 0 || (M * C * es) % vb != 0) return -1;
+  const long long nvec = M * C / (vb / es);
   if (nvec == 0) return 0;
-  const int vpr = C / (16 / es);
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(ew_blocks_chan(nvec, vpr)), dim3(256), 0,
-                                           st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec, C, 1,
-                                           (T*)dy, (T*)dres, (int)(nvec * 16 >= pda_stream_min_bytes()), cap));
+  const int vpr = C / (vb / es);
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, VB>), dim3(ew_blocks_chan(nvec, vpr)),
+                                                 dim3(256), 0, st, (const T*)dout, (const T*)y, (const T*)out, coef, nvec,
+                                                 C, 1, (T*)dy, (T*)dres, (int)(nvec * vb >= pda_stream_min_bytes()), cap));
   return pda_check_launch();
 }

@@ -400,7 +400,8 @@ def _sync_bn_ref(x, gamma, beta, st: BNState, mom):
 
 
 def batch_norm_act(y, gamma, beta, residual, relu, st: BNState):
-    if not y.is_cuda or y.shape[-1] % (16 // y.element_size()) != 0:
-        # CPU, or a channel count that does not fill 16-byte vectors (58, 122 in ShuffleNetV2): stock math
+    if not y.is_cuda or (y.shape[-1] * y.element_size()) % 4 != 0 or (y.numel() * y.element_size()) % 16 != 0:
+        # CPU, or an odd 16-bit channel count: stock math.  (Channel counts that do not fill 16-byte vectors - the
+        # 58 / 116 channels per branch of ShuffleNetV2 - run on the 4-byte-per-lane instantiations of the kernels.)
         return batch_norm_act_ref(y, gamma, beta, residual, relu, st)
     return _BatchNormActFn.apply(y, gamma, beta, residual, relu, st)

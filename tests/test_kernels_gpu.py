@@ -232,9 +232,15 @@ def test_direct_param_grads_and_arena():
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("relu,use_res", [(True, False), (True, True), (False, False)])
-def test_batchnorm_act_fwd_bwd(dtype, relu, use_res):
+@pytest.mark.parametrize("Cc", [64, 58, 116, 244, 6])
+def test_batchnorm_act_fwd_bwd(dtype, relu, use_res, Cc, monkeypatch):
+    """Stand-alone BatchNorm (+ residual) (+ ReLU), forward and backward, against torch's; channel counts that fill
+    16-byte vectors and ShuffleNetV2's 58 / 116 / 244, which run on the 4-byte-per-lane instantiations - on the
+    kernels either way, never on the stock fallback."""
+    from pytorch_distributed_amd.ops import norm as Nm
+    monkeypatch.setattr(Nm, "batch_norm_act_ref", lambda *a, **k: pytest.fail("stock fallback taken"))
     torch.manual_seed(5)
-    N, H, W, Cc = 4, 9, 9, 64
+    N, H, W = 4, 10, 10
     y = (torch.randn(N, H, W, Cc, device=DEV) * 2 + 0.5).to(dtype).requires_grad_(True)
     res = torch.randn(N, H, W, Cc, device=DEV).to(dtype).requires_grad_(True) if use_res else None
     bn = pnn.BatchNorm2d(Cc).to(DEV)
