@@ -94,14 +94,17 @@ __device__ __forceinline__ Vec16<T> load16_stream(const T* p) {
   return r;
 }
 
-// N-element vector of T: one 16-byte access when N*sizeof(T)==16, element-wise
-// otherwise (N=1 is the any-channel-count fallback of the pooling kernels).
+// N-element vector of T: one 16-byte access when N*sizeof(T)==16, one 4-byte access when N*sizeof(T)==4 (an even
+// count of 16-bit channels that does not fill 16-byte vectors), element-wise otherwise (N=1 is the
+// any-channel-count fallback of the pooling kernels).
 template <typename T, int N> struct VecN { T v[N]; };
 template <typename T, int N>
 __device__ __forceinline__ VecN<T, N> loadN(const T* p) {
   VecN<T, N> r;
   if constexpr (N * sizeof(T) == 16) {
     *reinterpret_cast<u32x4*>(&r) = *reinterpret_cast<const u32x4*>(p);
+  } else if constexpr (N * sizeof(T) == 4 && N > 1) {
+    *reinterpret_cast<unsigned*>(&r) = *reinterpret_cast<const unsigned*>(p);
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) r.v[i] = p[i];
@@ -112,6 +115,8 @@ template <typename T, int N>
 __device__ __forceinline__ void storeN(T* p, const VecN<T, N>& v) {
   if constexpr (N * sizeof(T) == 16) {
     *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(&v);
+  } else if constexpr (N * sizeof(T) == 4 && N > 1) {
+    *reinterpret_cast<unsigned*>(p) = *reinterpret_cast<const unsigned*>(&v);
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) p[i] = v.v[i];

@@ -211,11 +211,18 @@ static inline int dw_blocks(long long n) {
   if (b < 1) b = 1;
   return (int)b;
 }
-#define DW_DISPATCH(dtype, vec, CALL)                                                          \
+// epc: channels per lane access - 8 (4 for fp32) when the channel count fills 16-byte vectors, 2 for an even count of
+// 16-bit channels that does not (ShuffleNetV2's 58 / 116: one 4-byte access), 1 otherwise
+// (variadic: the launch macro expands to <<<a, b, c, d>>>, whose commas must not split the argument on the way down)
+#define DW_DISPATCH_16(epc, ...)                                         \
+  if ((epc) == 8) { constexpr int EPC = 8; __VA_ARGS__; }                \
+  else if ((epc) == 2) { constexpr int EPC = 2; __VA_ARGS__; }           \
+  else { constexpr int EPC = 1; __VA_ARGS__; }
+#define DW_DISPATCH(dtype, epc, ...)                                                           \
   switch (dtype) {                                                                             \
-    case PDA_F32: { typedef float T; if (vec) { constexpr int EPC = 4; CALL; } else { constexpr int EPC = 1; CALL; } } break; \
-    case PDA_F16: { typedef f16 T; if (vec) { constexpr int EPC = 8; CALL; } else { constexpr int EPC = 1; CALL; } } break;   \
-    case PDA_BF16: { typedef bf16 T; if (vec) { constexpr int EPC = 8; CALL; } else { constexpr int EPC = 1; CALL; } } break; \
+    case PDA_F32: { typedef float T; if ((epc) == 4) { constexpr int EPC = 4; __VA_ARGS__; } else { constexpr int EPC = 1; __VA_ARGS__; } } break; \
+    case PDA_F16: { typedef f16 T; DW_DISPATCH_16(epc, __VA_ARGS__) } break;                   \
+    case PDA_BF16: { typedef bf16 T; DW_DISPATCH_16(epc, __VA_ARGS__) } break;                 \
     default: return -6;                                                                        \
   }
 
@@ -232,21 +239,21 @@ PDA_EXPORT int pda_depthwise_conv(int dtype, int mode, const void* a, const void
   // the output size must be the one the geometry implies: the kernels index with it
   if (Ho != (Hi + 2 * ph - R) / sh + 1 || Wo != (Wi + 2 * pw - S) / sw + 1 || Hi + 2 * ph < R || Wi + 2 * pw < S)
     return -2;
-  const int epc = dtype == PDA_F32 ? 4 : 8;
-  const bool vec = (C % epc) == 0 && (reinterpret_cast<uintptr_t>(a) % 16) == 0 &&
-                   (reinterpret_cast<uintptr_t>(b) % 16) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out);
+  int epc = dtype == PDA_F32 ? 4 : 8;
+  if (C % epc != 0 || (ptrs % 16) != 0) epc = (dtype != PDA_F32 && C % 2 == 0 && (ptrs % 4) == 0) ? 2 : 1;
   DwGeom g{N, Hi, Wi, C, Ho, Wo, R, S, sh, sw, ph, pw};
   if (N == 0) return 0;
   if (mode == 0) {
-    const long long total = (long long)N * Ho * Wo * (C / (vec ? epc : 1));
-    DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_fprop_kernel<T, EPC>), dim3(dw_blocks(total)), dim3(256), 0, st,
+    const long long total = (long long)N * Ho * Wo * (C / epc);
+    DW_DISPATCH(dtype, epc, hipLaunchKernelGGL((dw_fprop_kernel<T, EPC>), dim3(dw_blocks(total)), dim3(256), 0, st,
                                                (const T*)a, (const T*)b, bias, (T*)out, g));
   } else if (mode == 1) {
-    const long long total = (long long)N * Hi * Wi * (C / (vec ? epc : 1));
-    DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_dgrad_kernel<T, EPC>), dim3(dw_blocks(total)), dim3(256), 0, st,
+    const long long total = (long long)N * Hi * Wi * (C / epc);
+    DW_DISPATCH(dtype, epc, hipLaunchKernelGGL((dw_dgrad_kernel<T, EPC>), dim3(dw_blocks(total)), dim3(256), 0, st,
                                                (const T*)a, (const T*)b, (T*)out, g));
   } else if (mode == 2) {
-    const int e = vec ? epc : 1;
+    const int e = epc;
     const int gx = (C / e + DW_CVB - 1) / DW_CVB;
     const long long M = (long long)N * Ho * Wo;
     long long ns = slabs;
@@ -261,13 +268,13 @@ PDA_EXPORT int pda_depthwise_conv(int dtype, int mode, const void* a, const void
     const unsigned gy = (unsigned)((M + slab - 1) / slab);
     const int use_atomic = gy > 1;
     if (S == 3) {
-      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 3>), dim3(gx, gy), dim3(256), 0, st,
+      DW_DISPATCH(dtype, epc, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 3>), dim3(gx, gy), dim3(256), 0, st,
                                                  (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
     } else if (S == 5) {
-      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 5>), dim3(gx, gy), dim3(256), 0, st,
+      DW_DISPATCH(dtype, epc, hipLaunchKernelGGL((dw_wgrad_row_kernel<T, EPC, 5>), dim3(gx, gy), dim3(256), 0, st,
                                                  (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
     } else {
-      DW_DISPATCH(dtype, vec, hipLaunchKernelGGL((dw_wgrad_kernel<T, EPC>), dim3(gx, gy), dim3(256), 0, st,
+      DW_DISPATCH(dtype, epc, hipLaunchKernelGGL((dw_wgrad_kernel<T, EPC>), dim3(gx, gy), dim3(256), 0, st,
                                                  (const T*)a, (const T*)b, (float*)out, g, slab, use_atomic));
     }
   } else {

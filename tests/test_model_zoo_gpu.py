@@ -134,9 +134,11 @@ def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("ch,k,stride,pad,hw,bias", [(96, 3, 1, 1, 14, False), (144, 3, 2, 1, 15, False),
                                                     (32, 5, 2, 2, 12, True), (20, 3, 1, 1, 9, False),
-                                                    (40, 7, 1, 3, 10, False)])
+                                                    (40, 7, 1, 3, 10, False), (58, 3, 2, 1, 13, False),
+                                                    (116, 3, 1, 1, 7, True), (21, 3, 1, 1, 8, False)])
 def test_depthwise_conv_matches_reference(dtype, ch, k, stride, pad, hw, bias):
-    """Depthwise kernels (vector path for channel counts that fill 16-byte vectors, scalar otherwise)
+    """Depthwise kernels (16-byte vectors for channel counts that fill them, channel pairs for the other even 16-bit
+    counts such as ShuffleNetV2's 58 / 116, single channels otherwise)
     == F.conv2d(groups=C) in fp32; also the single-slab (deterministic) weight gradient."""
     from pytorch_distributed_amd import backends
     torch.manual_seed(9)
