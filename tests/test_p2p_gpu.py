@@ -122,13 +122,6 @@ def test_hvd_optimizer_ranks_on_one_gpu(world):
     _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), world)
 
 
-@pytest.mark.parametrize("world", [2])
-def test_hvd_around_fused_optimizer_ranks_on_one_gpu(world):
-    """The Horovod wrapper around FusedSGD under amp O2 on a ResNet-18 (ops that accumulate gradients in place and
-    announce them themselves, weight gradients from the side stream): ranks end up with identical parameters."""
-    _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_fused_p2p_worker.py"), world)
-
-
 def test_bench_supervisor_with_two_ranks_sharing_the_gpu():
     """``python bench.py --gpus 2`` end to end on the one-GPU box: the supervisor starts two ranks through the
     package's launcher, both use GPU 0 (PDA_BENCH_SHARE_GPU=1) and reduce their buckets through the peer-memory
