@@ -65,16 +65,18 @@ def test_style5_horovod_mixed_precision_fused_optimizer(tmp_path):
     assert out.count(" * Acc@1") == 2
 
 
-def test_hvd_optimizer_combinations_one_gpu(tmp_path):
+def test_hvd_optimizer_combinations_one_gpu(tmp_path, monkeypatch):
     """hvd.DistributedOptimizer around the fused and the stock optimizer, with and without mixed precision, fp16
     compression and local accumulation (backward_passes_per_step): each trains (tests/workers/hvd_combos_gpu.py)."""
+    monkeypatch.setenv("MASTER_PORT", str(free_port()))
     out = run([sys.executable, os.path.join(ROOT, "tests", "workers", "hvd_combos_gpu.py")], tmp_path)
     assert out.count(" ok ") == 7 and "FAIL" not in out, out
 
 
-def test_ddp_combinations_one_gpu(tmp_path):
+def test_ddp_combinations_one_gpu(tmp_path, monkeypatch):
     """DistributedDataParallel (one rank, own RCCL communicator) with the fused and the stock optimizer, O0 / O1 / O2,
     no_sync() accumulation, the apex-flavoured wrapper and SyncBatchNorm: each trains (tests/workers/ddp_combos_gpu.py)."""
+    monkeypatch.setenv("MASTER_PORT", str(free_port()))   # the worker's rendezvous store listens there
     out = run([sys.executable, os.path.join(ROOT, "tests", "workers", "ddp_combos_gpu.py")], tmp_path)
     assert out.count(" ok ") == 10 and "FAIL" not in out, out
 
