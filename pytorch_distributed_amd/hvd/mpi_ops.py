@@ -365,7 +365,8 @@ def _fusion_buffer(dev, dtype, numel: int) -> torch.Tensor:
 def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
     """Called from the engine thread with one fused group of device tensors."""
     try:
-        ps = [_S.by_engine[int(handles_ptr[i])] for i in range(n)]
+        with _S.lock:   # a submitter registers its request under this lock, before the engine can hand it over
+            ps = [_S.by_engine[int(handles_ptr[i])] for i in range(n)]
         dev = ps[0].out.device
         if _S.side_stream is None:
             _S.side_stream = torch.cuda.Stream(dev)     # default priority: it waits for and is waited on by compute
@@ -461,10 +462,10 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
             p.wire, p.ctx = out, None
             p.event = torch.cuda.Event()
             p.event.record(torch.cuda.current_stream(out.device))
-            eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), 3, out.data_ptr(), out.numel(), _DT[out.dtype], 0, 0,
-                                        1, 1.0, 1.0)
-            p.eh = int(eh)
-            with _S.lock:
+            with _S.lock:   # the engine thread may pass the request to the executor as soon as it is enqueued
+                eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), 3, out.data_ptr(), out.numel(), _DT[out.dtype],
+                                            0, 0, 1, 1.0, 1.0)
+                p.eh = int(eh)
                 _S.by_engine[p.eh] = p
             return _new_handle(p)
         from .adasum import adasum_allreduce_
@@ -482,11 +483,11 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
         p.pre, p.post = float(prescale), float(postscale)
         p.event = torch.cuda.Event()
         p.event.record(torch.cuda.current_stream(out.device))
-        eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, out.data_ptr(), out.numel(),
-                                    _DT[wire_dt or out.dtype], _OP_CODE.get(op, 0), root, 1, float(prescale),
-                                    float(postscale))
-        p.eh = int(eh)
-        with _S.lock:
+        with _S.lock:   # (registered before the engine thread can pass it to the executor)
+            eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, out.data_ptr(), out.numel(),
+                                        _DT[wire_dt or out.dtype], _OP_CODE.get(op, 0), root, 1, float(prescale),
+                                        float(postscale))
+            p.eh = int(eh)
             _S.by_engine[p.eh] = p
         return _new_handle(p)
     wire, ctx = compression.compress(out)
@@ -515,10 +516,11 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
     if wire.is_cuda:
         p.event = torch.cuda.Event()
         p.event.record(torch.cuda.current_stream(wire.device))
-    eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, wire.data_ptr(), wire.numel(), _DT[wire.dtype],
-                                _OP_CODE.get(op, 0), root, 1 if wire.is_cuda else 0, float(prescale), float(postscale))
-    p.eh = int(eh)
     with _S.lock:
+        eh = _S.lib.pda_hvd_enqueue(_S.engine, name.encode(), kind, wire.data_ptr(), wire.numel(), _DT[wire.dtype],
+                                    _OP_CODE.get(op, 0), root, 1 if wire.is_cuda else 0, float(prescale),
+                                    float(postscale))
+        p.eh = int(eh)
         _S.by_engine[p.eh] = p
     return _new_handle(p)
 
@@ -636,10 +638,10 @@ def allgather_async(tensor, name=None, process_set=None) -> int:
     if t.is_cuda:
         p.event = torch.cuda.Event()
         p.event.record(torch.cuda.current_stream(t.device))
-    eh = _S.lib.pda_hvd_enqueue2(_S.engine, p.name.encode(), 2, t.data_ptr(), out.data_ptr(), t.numel(), _DT[t.dtype], 0,
-                                 0, 1 if t.is_cuda else 0, 1.0, 1.0)
-    p.eh = int(eh)
     with _S.lock:
+        eh = _S.lib.pda_hvd_enqueue2(_S.engine, p.name.encode(), 2, t.data_ptr(), out.data_ptr(), t.numel(),
+                                     _DT[t.dtype], 0, 0, 1 if t.is_cuda else 0, 1.0, 1.0)
+        p.eh = int(eh)
         _S.by_engine[p.eh] = p
     return _new_handle(p)
 

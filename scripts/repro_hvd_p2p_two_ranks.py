@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 os.environ.update(HOROVOD_RANK=str(rank), HOROVOD_SIZE=str(world), HOROVOD_LOCAL_RANK=str(rank),
                   HOROVOD_LOCAL_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                  PDA_HVD_NO_CUDA="1", PDA_HVD_DEVICE_COMM="p2p", PDA_HVD_P2P_DEVICE="0")
+                  PDA_HVD_NO_CUDA="1", PDA_HVD_DEVICE_COMM=os.environ.get("PDA_REPRO_DEVICE_COMM", "p2p"),
+                  PDA_HVD_P2P_DEVICE="0")
 import torch
 
 import pytorch_distributed_amd.hvd as hvd
