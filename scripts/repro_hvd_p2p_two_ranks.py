@@ -57,8 +57,18 @@ def main():
     same = bool(diff.max() == 0)
     differing = [names[i] for i in torch.nonzero(diff).flatten().tolist()][:6]
     finite = bool(torch.isfinite(flat).all())
+    try:    # a peer wait that timed out inside a kernel leaves results undefined and raises here
+        from pytorch_distributed_amd.hvd import mpi_ops as _M
+        dc = _M._S.dev_coll
+        if dc is not None:
+            torch.cuda.synchronize()
+            dc._ar.check()
+            dc._ts.check()
+        flags = "no kernel-side timeouts"
+    except Exception as e:  # noqa: BLE001
+        flags = f"kernel-side error flag: {e}"
     ok = same and finite and losses[-1] < losses[0] and all(l == l for l in losses)
-    print(f"rank {rank}: {'OK' if ok else 'FAILED'} ranks agree {same} {differing}, finite {finite}, loss "
+    print(f"rank {rank}: {'OK' if ok else 'FAILED'} ranks agree {same} {differing}, finite {finite}, {flags}, loss "
           f"{losses[0]:.3f} -> {losses[-1]:.3f}", flush=True)
     hvd.shutdown()
     return 0 if ok else 1
