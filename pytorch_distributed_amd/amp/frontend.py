@@ -162,12 +162,53 @@ def _grads_of(optimizer):
     return [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
 
 
+def _overflow_check(opt, scaler: LossScaler) -> None:
+    """Run the unscale / overflow pass over the gradients ``opt`` is going to consume.
+
+    A fused optimizer divides by the loss scale inside its update kernel, so for it the pass only reads
+    (``check_only``: it must not write a gradient back, since it has no business changing one)."""
+    grads = _grads_of(opt)
+    if not grads:
+        return
+    by_dtype = {}
+    for g in grads:
+        by_dtype.setdefault(g.dtype, []).append(g)
+    fused = hasattr(opt, "attach_scaler")
+    for gl in by_dtype.values():
+        key = ("amp_unscale", tuple(g.data_ptr() for g in gl))
+        cache = opt.__dict__.setdefault("_amp_tl_cache", {})
+        tl = cache.get(key)
+        if tl is None:
+            if len(cache) > 16:
+                cache.clear()
+            tl = cache[key] = mt.TensorLists([gl, gl])
+        if fused:
+            mt.scale(tl, 1.0, noop_flag=scaler.overflow_flag, check_only=True)
+        else:
+            mt.scale(tl, 1.0, dev_scale=scaler.scale_tensor, invert=True, noop_flag=scaler.overflow_flag)
+    scaler.grads_scaled = fused
+
+
+def _finish_reductions(opt) -> None:
+    """Gradient reductions an optimizer wrapper launched from backward hooks and only waits for inside
+    ``step()`` (``hvd.DistributedOptimizer``) have to be finished BEFORE the overflow pass: the pass must see
+    the reduced gradients - every rank then takes the same skip decision - and must not run next to the
+    engine's unpack kernels that are still replacing ``p.grad``.  This is Horovod's recipe for apex amp
+    (``optimizer.synchronize()`` inside ``scale_loss``, ``skip_synchronize()`` around ``step()``), done here
+    so that the reference's plain ``scale_loss`` + ``step()`` loop
+    (/root/reference/4.apex_distributed2.py:289-291 on /root/reference/5.horovod_distributed.py:125) is right."""
+    sync = getattr(opt, "synchronize", None)
+    if callable(sync) and hasattr(opt, "_handles"):
+        sync()
+        opt._synchronized_by_amp = True
+
+
 @contextlib.contextmanager
 def scale_loss(loss: torch.Tensor, optimizers, loss_id: int = 0, delay_unscale: bool = False):
     """Yield ``loss * scale``; on exit unscale the gradients in place and record overflow.
 
     With a fused optimizer the unscale is deferred into the update kernel: the exit
-    only runs the overflow check (one read pass over the gradients), so the grads
+    only runs the overflow check (one read-only pass over the gradients), so the grads
     seen between the context manager and ``optimizer.step()`` are still scaled
     unless ``PDA_AMP_EAGER_UNSCALE=1`` / ``delay_unscale=False`` on a stock optimizer.
     """
@@ -182,27 +223,8 @@ def scale_loss(loss: torch.Tensor, optimizers, loss_id: int = 0, delay_unscale: 
         scaler.grads_scaled = True
         return
     for opt in opts:
-        grads = _grads_of(opt)
-        if not grads:
-            continue
-        by_dtype = {}
-        for g in grads:
-            by_dtype.setdefault(g.dtype, []).append(g)
-        fused = hasattr(opt, "attach_scaler")
-        for gl in by_dtype.values():
-            key = ("amp_unscale", tuple(g.data_ptr() for g in gl))
-            cache = opt.__dict__.setdefault("_amp_tl_cache", {})
-            tl = cache.get(key)
-            if tl is None:
-                if len(cache) > 16:
-                    cache.clear()
-                tl = cache[key] = mt.TensorLists([gl, gl])
-            if fused:
-                # check only (scale by 1, in place): the division by the loss scale happens in the update kernel
-                mt.scale(tl, 1.0, noop_flag=scaler.overflow_flag)
-            else:
-                mt.scale(tl, 1.0, dev_scale=scaler.scale_tensor, invert=True, noop_flag=scaler.overflow_flag)
-        scaler.grads_scaled = fused
+        _finish_reductions(opt)
+        _overflow_check(opt, scaler)
 
 
 def state_dict() -> dict:

@@ -40,6 +40,19 @@ class _DoneWork:
         return True
 
 
+class _DoneWork:
+    """Work handle of a collective that had finished when the call returned."""
+
+    def wait(self):
+        return True
+
+    def is_completed(self) -> bool:
+        return True
+
+    def synchronize(self, timeout_s: float = 0.0) -> bool:
+        return True
+
+
 class TorchCollectives:
     """Adapter over an initialised ``torch.distributed`` process group."""
 
@@ -55,16 +68,41 @@ class TorchCollectives:
         d = self._dist
         return d.get_global_rank(self.group, r) if hasattr(d, "get_global_rank") else r
 
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """Device tensors on a group without device collectives (gloo) are staged through the host here, in
+        the caller's stream order and synchronously: the group's own handling of device memory is not relied
+        on (two ranks handing it device tensors from their engine threads never finished their first step)."""
+        return t.is_cuda and not self.device_collectives
+
     def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
         d = self._dist
+        if self._host_staged(t):
+            h = t.detach().to("cpu", torch.float32 if t.dtype in (torch.float16, torch.bfloat16) else t.dtype)
+            rop = {"sum": d.ReduceOp.SUM, "prod": d.ReduceOp.PRODUCT, "min": d.ReduceOp.MIN, "max": d.ReduceOp.MAX,
+                   "avg": d.ReduceOp.SUM}[op]
+            d.all_reduce(h, op=rop, group=self.group)
+            if op == "avg":
+                h /= self.world_size
+            t.copy_(h)
+            return _DoneWork() if async_op else None
         rop = {"sum": d.ReduceOp.SUM, "prod": d.ReduceOp.PRODUCT, "min": d.ReduceOp.MIN, "max": d.ReduceOp.MAX,
                "avg": d.ReduceOp.AVG}[op]
         return d.all_reduce(t, op=rop, group=self.group, async_op=async_op)
 
     def broadcast(self, t: torch.Tensor, src: int = 0, async_op: bool = False):
+        if self._host_staged(t):
+            h = t.detach().cpu()
+            self._dist.broadcast(h, src=self._global(src), group=self.group)
+            t.copy_(h)
+            return _DoneWork() if async_op else None
         return self._dist.broadcast(t, src=self._global(src), group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, t: torch.Tensor, async_op: bool = False):
+        if self._host_staged(t):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            self._dist.all_gather_into_tensor(ho, t.detach().cpu().contiguous(), group=self.group)
+            out.copy_(ho)
+            return _DoneWork() if async_op else None
         return self._dist.all_gather_into_tensor(out, t, group=self.group, async_op=async_op)
 
     def reduce_scatter(self, out: torch.Tensor, t: torch.Tensor, op: str = "sum", async_op: bool = False):

@@ -13,7 +13,10 @@
 //   scale : out = in * scale, sets *noop_flag if any input is inf/nan or a value
 //           leaves the range of a narrower output type (grad unscale + overflow
 //           check in one pass; with scale=1 it is the cast / flatten / unflatten
-//           kernel: out pointers may be views of a bucket)
+//           kernel: out pointers may be views of a bucket).  Bit 1 of `invert`
+//           makes it a pure check: nothing is stored, so the pass cannot write a
+//           stale value over a gradient that another stream is replacing with its
+//           all-reduced form
 //   axpby : out = a*x + b*y with the same finite check
 //   l2norm: per-tensor and global sum of squares
 //   sgd   : unscale + overflow-skip + weight decay + momentum (+nesterov) + update
@@ -69,7 +72,8 @@ mt_scale_kernel(const long long* __restrict__ meta, const int* __restrict__ blk,
   TO* out = reinterpret_cast<TO*>(meta[ti * 3 + 1]);
   const long long n = meta[ti * 3 + 2];
   float sc = scale;
-  if (dev_scale) sc *= invert ? 1.f / *dev_scale : *dev_scale;
+  const bool check_only = (invert & 2) != 0;
+  if (dev_scale) sc *= (invert & 1) ? 1.f / *dev_scale : *dev_scale;
   const bool al = al4<TI>(in) && al4<TO>(out);
   const long long beg = (long long)ci * MT_CHUNK;
   const long long end = beg + MT_CHUNK < n ? beg + MT_CHUNK : n;
@@ -83,7 +87,7 @@ mt_scale_kernel(const long long* __restrict__ meta, const int* __restrict__ blk,
       // a finite fp32 value beyond the fp16 range becomes inf on the store: flag that as well
       bad = bad || !isfinite(sizeof(TO) < sizeof(TI) ? ElemTraits<TO>::to_f32(ElemTraits<TO>::from_f32(v[k])) : v[k]);
     }
-    st4<TO>(out, i, end, al, v);
+    if (!check_only) st4<TO>(out, i, end, al, v);
   }
   if (noop_flag && __any(bad)) {
     if ((threadIdx.x & 63) == 0) *noop_flag = 1;

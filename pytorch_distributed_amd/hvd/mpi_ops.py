@@ -362,12 +362,55 @@ def _fusion_buffer(dev, dtype, numel: int) -> torch.Tensor:
     return buf
 
 
+# test hook: the engine thread sleeps this long before it launches a group, which keeps every reduction "in
+# flight" well past the end of backward (tests/workers/hvd_amp_p2p_worker.py)
+_TEST_EXEC_DELAY_MS = float(os.environ.get("PDA_HVD_TEST_EXEC_DELAY_MS", "0") or 0)
+
+
+class _Diag:
+    """``PDA_HVD_DIAG=<dir>``: per-rank record of every fused device group - ordered member names with their
+    offsets in the fusion buffer and an fp64 checksum per member (a) after the pack, (b) after the all-reduce,
+    (c) in the destination tensor after the unpack - plus (d) the gradients an ``hvd.DistributedOptimizer`` hands
+    to the wrapped ``step()``.  (b) must be identical on all ranks; ``scripts/hvd_diag_diff.py`` compares the
+    files.  Every checkpoint drains the stream it reads: a diagnosis aid, not a production mode."""
+    dir = os.environ.get("PDA_HVD_DIAG", "")
+    fh = None
+    group = 0
+    step = 0
+
+    @classmethod
+    def on(cls) -> bool:
+        return bool(cls.dir)
+
+    @classmethod
+    def write(cls, rec: dict) -> None:
+        import json
+        if cls.fh is None:
+            os.makedirs(cls.dir, exist_ok=True)
+            cls.fh = open(os.path.join(cls.dir, f"rank{_S.info.rank}.jsonl"), "a")
+        cls.fh.write(json.dumps(rec) + "\n")
+        cls.fh.flush()
+
+    @staticmethod
+    def sums(tensors) -> list:
+        # position-weighted so that two members trading places, or a shifted slice, change the value
+        out = []
+        for t in tensors:
+            f = torch.as_strided(t, (t.numel(),), (1,)).double()
+            w = torch.arange(1, f.numel() + 1, device=f.device, dtype=torch.float64)
+            out.append(float((f * (1.0 + w / f.numel())).sum().item()))
+        return out
+
+
 def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
     """Called from the engine thread with one fused group of device tensors."""
     try:
         with _S.lock:   # a submitter registers its request under this lock, before the engine can hand it over
             ps = [_S.by_engine[int(handles_ptr[i])] for i in range(n)]
         dev = ps[0].out.device
+        if _TEST_EXEC_DELAY_MS and kind == 0:
+            import time
+            time.sleep(_TEST_EXEC_DELAY_MS / 1000.0)
         if _S.side_stream is None:
             _S.side_stream = torch.cuda.Stream(dev)     # default priority: it waits for and is waited on by compute
         launches = 0
@@ -415,13 +458,31 @@ def _device_executor(kind, n, handles_ptr, op_code, root) -> int:
                         for o in outs:
                             views.append(flat[off:off + o.numel()])
                             off += o.numel()
-                        tabs = (mt.TensorLists([outs, views]), mt.TensorLists([views, outs]))
+                        # frozen: keyed by addresses, holding no tensors - with zero_grad(set_to_none=True) every step
+                        # brings new gradient tensors, and a cache of live references would pin the old ones
+                        tabs = (mt.TensorLists([outs, views]).freeze(), mt.TensorLists([views, outs]).freeze())
                         if len(_S.group_tables) > 256:
                             _S.group_tables.clear()
                         _S.group_tables[gkey] = tabs
+                    if _Diag.on():
+                        offs, off = [], 0
+                        for o in outs:
+                            offs.append(off)
+                            off += o.numel()
+                        views_d = [flat[a:a + o.numel()] for a, o in zip(offs, outs)]
+                        rec = {"group": _Diag.group, "step": _Diag.step, "names": [p.name for p in ps], "offsets": offs,
+                               "numels": [o.numel() for o in outs], "wire": str(wire_dt), "pre": pre, "post": post}
+                        _Diag.group += 1
                     mt.scale(tabs[0], pre)              # pack + cast to the wire dtype + pre-scale: one launch
+                    if _Diag.on():
+                        rec["a_packed"] = _Diag.sums(views_d)
                     coll.all_reduce(flat[:total], rname, **kw)
+                    if _Diag.on():
+                        rec["b_reduced"] = _Diag.sums(views_d)
                     mt.scale(tabs[1], post)             # unpack + cast back + average / post-scale: one launch
+                    if _Diag.on():
+                        rec["c_unpacked"] = _Diag.sums(outs)
+                        _Diag.write(rec)
                     launches += 3
             for p in ps:
                 p.event = torch.cuda.Event()

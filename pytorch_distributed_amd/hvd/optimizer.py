@@ -45,6 +45,7 @@ class _Reducing:
         self.gradient_predivide_factor = float(gradient_predivide_factor)
         self._handles = {}
         self._synchronized = False
+        self._synchronized_by_amp = False
         self._should_synchronize = True
         self._reduced_params = [p for p in params if p.requires_grad]
         self._direct_fired = set()
@@ -53,8 +54,24 @@ class _Reducing:
         # ``.grad`` (no AccumulateGrad node, so no autograd hook): they announce such a gradient through
         # ``_pda_grad_ready`` instead, which keeps the reduction overlapped with the rest of backward.
         for p in self._reduced_params:
-            if not hasattr(p, "_pda_grad_ready"):
-                p._pda_grad_ready = self._make_direct_ready(p)
+            ddp = getattr(p, "_pda_ddp", None)
+            if ddp is not None and ddp() is not None:
+                continue            # a live DistributedDataParallel wrapper owns this parameter's announcements
+            old = getattr(getattr(p, "_pda_grad_ready", None), "_hvd_owner", None)
+            old = old() if old is not None else None
+            if old is not None and old is not self:
+                old._hvd_release()  # a re-wrap (resume, second wrapper in one process): the old wrapper lets go
+            p._pda_grad_ready = self._make_direct_ready(p)
+
+    def _hvd_release(self):
+        """Detach from the parameters: remove the autograd hooks and the direct-announcement callbacks."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self._reduced_params:
+            if getattr(getattr(p, "_pda_grad_ready", None), "_hvd_owner", None) is not None \
+                    and p._pda_grad_ready._hvd_owner() is self:
+                del p._pda_grad_ready
 
     def _make_direct_ready(self, p):
         def ready():
@@ -72,6 +89,8 @@ class _Reducing:
             else:
                 self._hvd_hook(p)
             self._direct_fired.add(p)
+        import weakref
+        ready._hvd_owner = weakref.ref(self)
         return ready
 
     def _hvd_autograd_hook(self, p):
@@ -129,12 +148,26 @@ class _Reducing:
 
     def step(self, closure=None):
         if self._should_synchronize:
-            if self._synchronized:
-                warnings.warn("optimizer.step() after optimizer.synchronize() without skip_synchronize(): "
-                              "gradients are reduced twice as slowly as needed")
-            self.synchronize()
+            if self._synchronized_by_amp and not self._pending_work():
+                pass    # amp.scale_loss has already waited for this step's reductions (before its overflow check)
+            else:
+                if self._synchronized:
+                    warnings.warn("optimizer.step() after optimizer.synchronize() without skip_synchronize(): "
+                                  "gradients are reduced twice as slowly as needed")
+                self.synchronize()
         self._synchronized = False
+        self._synchronized_by_amp = False
+        if M._Diag.on():
+            ps = [p for p in self._reduced_params if p.grad is not None]
+            if ps and ps[0].grad.is_cuda:
+                torch.cuda.synchronize()
+            M._Diag.step += 1
+            M._Diag.write({"step": M._Diag.step - 1, "step_grads": {self._name_of.get(p, "?"): v
+                                          for p, v in zip(ps, M._Diag.sums([p.grad for p in ps]))}})
         return super().step(closure)
+
+    def _pending_work(self) -> bool:
+        return any(h is not None for h in self._handles.values())
 
     def _hvd_super_step(self, closure=None):
         """The wrapped optimizer's own step, without gradient reduction (state materialisation in
@@ -156,5 +189,13 @@ def DistributedOptimizer(optimizer, named_parameters=None, compression=M.Compres
     cls = type(base.__name__, (_Reducing, base), {})
     obj = cls.__new__(cls)
     obj.__dict__.update(optimizer.__dict__)     # share param_groups / state / hyper-parameters with the wrapped one
+    if obj.__dict__.get("_amp_patched") and "step" in obj.__dict__:
+        # amp.initialize() patched the wrapped optimizer's instance with a step() that checks the overflow flag and
+        # then calls the wrapped step directly; copied as it is, it would shadow this class's step() and with it
+        # synchronize().  Patch the wrapper instead: flag check -> synchronize -> wrapped step
+        del obj.__dict__["step"]
+        obj._amp_patched = False
+        from ..amp.frontend import _attach
+        _attach(obj, obj._amp_scaler_ref)
     obj._hvd_setup(named_parameters, compression, backward_passes_per_step, op, gradient_predivide_factor)
     return obj

@@ -45,7 +45,19 @@ class TensorLists:
     def dtypes(self):
         return [l[0].dtype if l else torch.float32 for l in self.lists]
 
+    def freeze(self) -> "TensorLists":
+        """Build the device tables now and drop the references to the tensors (only one empty tensor per list
+        stays, for its dtype).  A cache of frozen tables keyed by the tensors' addresses does not keep gradient
+        storage alive; the caller guarantees the addresses are live whenever the tables are used."""
+        if self.is_cuda and self.lists[0]:
+            self.tables()
+            self.lists = [[l[0].new_empty(0)] for l in self.lists]
+            self._frozen = True
+        return self
+
     def tables(self):
+        if getattr(self, "_frozen", False):
+            return self._meta, self._blk, self.nblocks
         ptrs = tuple(t.data_ptr() for l in self.lists for t in l)
         if self._meta is None or ptrs != self._ptrs:
             L = len(self.lists)
@@ -73,8 +85,10 @@ def _flat(t: torch.Tensor) -> torch.Tensor:
 
 
 def scale(tl: TensorLists, scale_value: float = 1.0, dev_scale: Optional[torch.Tensor] = None,
-          invert: bool = False, noop_flag: Optional[torch.Tensor] = None) -> None:
-    """lists[1][i] = lists[0][i] * scale (* dev_scale or / dev_scale); flags non-finite inputs."""
+          invert: bool = False, noop_flag: Optional[torch.Tensor] = None, check_only: bool = False) -> None:
+    """lists[1][i] = lists[0][i] * scale (* dev_scale or / dev_scale); flags non-finite inputs.
+
+    ``check_only`` reads and flags but stores nothing (the overflow check in front of a fused optimizer)."""
     src, dst = tl.lists[0], tl.lists[1]
     if not src:
         return
@@ -82,8 +96,8 @@ def scale(tl: TensorLists, scale_value: float = 1.0, dev_scale: Optional[torch.T
         meta, blk, nb = tl.tables()
         l = _lib.lib()
         _lib.check(l.pda_mt_scale(_lib.dt(src[0]), _lib.dt(dst[0]), meta.data_ptr(), blk.data_ptr(), nb,
-                                  float(scale_value), _lib.ptr(dev_scale), int(invert), _lib.ptr(noop_flag),
-                                  _lib.stream()), "pda_mt_scale")
+                                  float(scale_value), _lib.ptr(dev_scale), int(bool(invert)) | (2 if check_only else 0),
+                                  _lib.ptr(noop_flag), _lib.stream()), "pda_mt_scale")
         return
     s = float(scale_value)
     if dev_scale is not None:
@@ -92,6 +106,8 @@ def scale(tl: TensorLists, scale_value: float = 1.0, dev_scale: Optional[torch.T
     for a, b in zip(src, dst):
         af = _flat(a).float()
         bad = bad or not bool(torch.isfinite(af).all())
+        if check_only:
+            continue
         _flat(b).copy_(af * s)
         if b.dtype != a.dtype and b.element_size() < a.element_size():
             bad = bad or not bool(torch.isfinite(_flat(b).float()).all())

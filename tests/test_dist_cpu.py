@@ -144,3 +144,14 @@ def test_hvd_api_two_ranks():
                        cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("hvd OK") == 2
+
+
+@pytest.mark.parametrize("kind", ["fused", "stock"])
+def test_hvd_with_amp_skips_overflowed_step_on_every_rank(kind):
+    """scale_loss waits for the wrapper's reductions before its overflow pass: an infinity on one rank makes all
+    ranks skip; also the amp-patched step() of a stock optimizer keeps going through synchronize()."""
+    r = subprocess.run([sys.executable, "-m", "pytorch_distributed_amd.launch", "-np", "2", "-H", "localhost:2",
+                        "--master_port", str(free_port()), os.path.join(ROOT, "tests", "workers", "hvd_amp_worker.py"),
+                        kind], cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("hvd amp OK") == 2

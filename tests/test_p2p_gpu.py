@@ -122,6 +122,30 @@ def test_hvd_optimizer_ranks_on_one_gpu(world):
     _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_p2p_worker.py"), world)
 
 
+@pytest.mark.parametrize("mode", ["fused", "overflow", "legacy-overflow"])
+def test_hvd_fused_optimizer_under_amp_ranks_on_one_gpu(mode):
+    """amp.scale_loss + hvd.DistributedOptimizer(FusedSGD, fp16 compression) on a ResNet-18 whose fused ops
+    announce their gradients themselves, with the engine thread slowed down so that every reduction is in flight
+    when backward returns.  ``fused``: identical parameters after four steps.  ``overflow``: an infinity on one
+    rank makes all ranks skip.  ``legacy-overflow``: the same input through the old order (overflow pass first,
+    reductions waited for in step()) must show the ranks disagreeing - deterministically, thanks to the delay."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "hvd_amp_p2p_worker.py"), 2, extra=(mode,))
+
+
+def test_overflow_check_stores_nothing():
+    import torch
+    from pytorch_distributed_amd.ops import multi_tensor as mt
+    src = [torch.randn(70001, device="cuda"), torch.randn(5, device="cuda").half()]
+    for dt_group in ([src[0]], [src[1]]):
+        dst = [torch.full_like(t, 7.0) for t in dt_group]
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        mt.scale(mt.TensorLists([dt_group, dst]), 3.0, noop_flag=flag, check_only=True)
+        assert all(bool((d == 7.0).all()) for d in dst) and int(flag) == 0
+        dt_group[0][3] = float("inf")
+        mt.scale(mt.TensorLists([dt_group, dst]), 3.0, noop_flag=flag, check_only=True)
+        assert all(bool((d == 7.0).all()) for d in dst) and int(flag) == 1
+
+
 def test_bench_supervisor_with_two_ranks_sharing_the_gpu():
     """``python bench.py --gpus 2`` end to end on the one-GPU box: the supervisor starts two ranks through the
     package's launcher, both use GPU 0 (PDA_BENCH_SHARE_GPU=1) and reduce their buckets through the peer-memory
