@@ -50,9 +50,21 @@ def parse(argv=None):
     ap.add_argument("--num-classes", type=int, default=1000)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--opt-level", default="O2", choices=["O0", "O1", "O2", "O3"])
-    ap.add_argument("--engine", default="native", choices=["native", "stock"],
-                    help="native = this framework's kernels/DDP/AMP; stock = plain PyTorch-ROCm comparator")
-    ap.add_argument("--bucket-mb", type=float, default=25.0)
+    ap.add_argument("--engine", default="native", choices=["native", "hvd", "stock"],
+                    help="native = this framework's kernels + DistributedDataParallel + AMP; hvd = the same kernels "
+                         "under the Horovod-compatible API (hvd.init, broadcast_parameters / optimizer_state, "
+                         "hvd.DistributedOptimizer with fp16 compression: /root/reference/5.horovod_distributed.py:"
+                         "116-125); stock = plain PyTorch-ROCm comparator")
+    ap.add_argument("--bucket-mb", default="25",
+                    help="DDP bucket size in MiB; a comma list (8,16,25,32,64) times every value in this one "
+                         "invocation, reports them as bucket_sweep and takes the best as the headline")
+    ap.add_argument("--eval-steps", type=int, default=0,
+                    help="after the training timing: this many forward-only steps in eval mode whose loss / accuracy "
+                         "sums stay on the device and cross the ranks in ONE fused all-reduce at the end (the "
+                         "distributed evaluation of /root/reference/5.horovod_distributed.py:231-272)")
+    ap.add_argument("--selftest", action="store_true",
+                    help="before timing, run all_reduce (fp16 and fp32, 1 KB and 32 MB), broadcast, all_gather and "
+                         "barrier on the data-plane communicator against closed-form values")
     ap.add_argument("--comm", default="auto", choices=["auto", "native", "torch", "p2p2"],
                     help="gradient all-reduce back-end: native = this package's RCCL communicator with its own "
                          "comm stream (auto picks it on GPUs), torch = torch.distributed's process group, "
@@ -71,14 +83,26 @@ def parse(argv=None):
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap the model in DistributedDataParallel even for one rank (exercises the bucketed "
                          "all-reduce path on a single GPU)")
-    ap.add_argument("--compare-stock", action="store_true",
+    ap.add_argument("--compare-stock", action=argparse.BooleanOptionalAction, default=None,
                     help="after the native timing, time the stock PyTorch-ROCm engine (channels-last autocast + "
                          "GradScaler + torch SGD, same model / batch / steps) in the same process and report "
-                         "vs_stock = native / stock")
+                         "vs_stock = native / stock.  Default: on for a single-GPU native run of at most 40 timed "
+                         "steps (the comparator then adds a few seconds), off otherwise")
     ap.add_argument("--stage-timeout", type=float, default=float(os.environ.get("PDA_BENCH_STAGE_TIMEOUT", "300")),
                     help="seconds any single blocking stage may take before the run is declared hung")
     ap.add_argument("--master-port", type=int, default=0, help="supervisor mode: rendezvous port (0 = pick a free one)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    try:
+        args.bucket_list = [float(v) for v in str(args.bucket_mb).split(",") if v.strip() != ""]
+    except ValueError:
+        ap.error(f"--bucket-mb: not a number or comma list of numbers: {args.bucket_mb!r}")
+    if not args.bucket_list or any(v <= 0 for v in args.bucket_list):
+        ap.error("--bucket-mb needs positive sizes")
+    args.bucket_mb = args.bucket_list[0]
+    if args.compare_stock is None:
+        args.compare_stock = (args.gpus == 1 and args.engine == "native" and args.steps <= 40 and not args.force_ddp
+                              and os.environ.get("PDA_BENCH_DEVICE", "") != "cpu")
+    return args
 
 
 # ------------------------------------------------------------------------------------------------
@@ -282,6 +306,18 @@ def worker(args) -> int:
                 # torch only creates an RCCL communicator of its own if something hands it a device tensor
                 pcomm.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=to)
 
+    watchdog = None
+    if ddp and not on_cpu or (ddp and os.environ.get("PDA_BENCH_WATCHDOG", "") == "1"):
+        # heartbeats through the rendezvous store (+ the communicator's asynchronous error state once it exists): a
+        # rank that dies ends the job with a non-zero exit code instead of leaving the others in their next collective
+        from pytorch_distributed_amd.comm.watchdog import start_watchdog
+
+        def _peer_failure(reason):
+            print(json.dumps({"error": f"rank {rank}: watchdog: {reason}", "stage": "watchdog", "rank": rank}),
+                  flush=True)
+            os._exit(75)
+        watchdog = start_watchdog(on_failure=_peer_failure)
+
     from pytorch_distributed_amd import models, ops, amp, backends
     backends.benchmark = bool(args.autotune) and args.warmup > 0   # the tuning runs belong to the warm-up steps
     from pytorch_distributed_amd.optim import FusedSGD
@@ -299,6 +335,8 @@ def worker(args) -> int:
         """This package's RCCL communicator, created and proven with one bounded collective before the model
         depends on it.  Every rank votes (over the gloo control plane) on whether it works; a single failing or
         stalling rank sends the whole job to torch.distributed's process group instead, and the JSON says so."""
+        if "native_kind" in comm_info:
+            return comm_info["native_kind"]
         ok, why, c = 1, "", None
         with deadline.stage("RCCL communicator creation", factor=1.0):
             try:
@@ -326,7 +364,11 @@ def worker(args) -> int:
             if world > 1:
                 dist.all_reduce(v, op=dist.ReduceOp.MIN)
         if int(v.item()) == 1:
+            comm_info["native_kind"] = c
+            if watchdog is not None:
+                watchdog.comm = c
             return c
+        comm_info["native_kind"] = "torch"
         comm_info["comm_fallback_reason"] = why or "another rank could not use the native communicator"
         print(f"[bench] rank {rank}: native RCCL communicator unusable ({comm_info['comm_fallback_reason']}); "
               "falling back to torch.distributed", file=sys.stderr, flush=True)
@@ -338,8 +380,9 @@ def worker(args) -> int:
             pcomm._STATE["rccl"].clear()
         return "torch"
 
-    def build_native():
+    def build_native(bucket_mb=None):
         nonlocal comm_obj
+        bucket_mb = args.bucket_mb if bucket_mb is None else bucket_mb
         model = models.get_model(args.arch, num_classes=args.num_classes).to(dev)
         if args.sync_bn:
             from pytorch_distributed_amd.nn import SyncBatchNorm
@@ -354,7 +397,7 @@ def worker(args) -> int:
             if kind == "native":
                 kind = make_native_comm()
             with deadline.stage("parameter broadcast"):
-                model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=args.bucket_mb,
+                model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=bucket_mb,
                             force_comm=args.force_ddp, comm=kind, wire_dtype=args.wire_dtype)
                 comm_obj = model._coll
                 if not on_cpu:
@@ -378,6 +421,119 @@ def worker(args) -> int:
             opt.step()
             return loss
         return model, step
+
+    hvd_info = {}
+
+    def build_hvd():
+        """The loop of /root/reference/5.horovod_distributed.py:116-125,219-221 on this package's hvd module."""
+        nonlocal comm_obj
+        import pytorch_distributed_amd.hvd as hvd
+        with deadline.stage("hvd.init"):
+            hvd.init()
+            if hvd.size() != world:
+                raise RuntimeError(f"hvd.size() = {hvd.size()}, expected {world}")
+        model = models.get_model(args.arch, num_classes=args.num_classes).to(dev)
+        if args.sync_bn:
+            from pytorch_distributed_amd.nn import SyncBatchNorm
+            SyncBatchNorm.convert_sync_batchnorm(model)
+        with deadline.stage("hvd.broadcast_parameters"):
+            hvd.broadcast_parameters(model.state_dict(), root_rank=0)
+        opt = FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        level = "O0" if args.precision == "fp32" else args.opt_level
+        model, opt = amp.initialize(model, opt, opt_level=level, dtype=cdtype if level != "O0" else torch.float16,
+                                    verbosity=0)
+        with deadline.stage("hvd.broadcast_optimizer_state"):
+            hvd.broadcast_optimizer_state(opt, root_rank=0)
+        compression = {"fp16": hvd.Compression.fp16, "bf16": hvd.Compression.bf16}.get(
+            args.precision if args.wire_dtype == "auto" else args.wire_dtype, hvd.Compression.none)
+        opt = hvd.DistributedOptimizer(opt, named_parameters=model.named_parameters(), compression=compression)
+        from pytorch_distributed_amd.hvd import mpi_ops as _M
+        dc = _M._device_coll(dev) if world > 1 and not on_cpu else None
+        comm_obj = dc if (dc is not None and hasattr(dc, "nranks")) else None
+        comm_info["comm_backend"] = "hvd engine / " + (getattr(dc, "backend", type(dc).__name__) if dc is not None
+                                                       else ("shm" if world > 1 else "single process"))
+        comm_info["wire_dtype"] = getattr(compression, "wire", None) and str(compression.wire).replace("torch.", "")
+        if watchdog is not None and comm_obj is not None:
+            watchdog.comm = comm_obj
+        hvd_info["hvd"] = hvd
+        metrics = ops.new_metrics(dev)
+
+        def step():
+            opt.zero_grad()
+            loss = ops.cross_entropy(model(images), target, metrics)
+            with amp.scale_loss(loss, opt) as scaled:
+                scaled.backward()
+            opt.step()
+            return loss
+        return model, step
+
+    def selftest(coll):
+        """Every collective of the data plane once, against closed-form values, before anything is timed."""
+        import math
+        w = world
+        tri = w * (w + 1) / 2
+        tests = []
+        for dt_, name in ((torch.float32, "fp32"), (torch.float16, "fp16")):
+            for n, sz in ((256 if dt_ == torch.float32 else 512, "1KB"), ((8 << 20) if dt_ == torch.float32 else (16 << 20), "32MB")):
+                tests.append((f"all_reduce {name} {sz}", dt_, n))
+        for label, dt_, n in tests:
+            with deadline.stage("selftest " + label):
+                t = torch.full((n,), float(rank + 1), device=dev, dtype=dt_)
+                t[-1] = float(rank)         # the last element differs from the rest: a shifted slice shows
+                coll.all_reduce(t, "sum")
+                if not on_cpu:
+                    torch.cuda.synchronize()
+                got = (float(t[0]), float(t[n // 2]), float(t[-1]), float(t.float().sum() - float(t[-1])))
+                want = (tri, tri, w * (w - 1) / 2, tri * (n - 1))
+                if not all(math.isclose(g, e, rel_tol=2e-3, abs_tol=1e-3) for g, e in zip(got, want)):
+                    return f"{label}: got {got}, expected {want}"
+        with deadline.stage("selftest broadcast"):
+            t = torch.arange(4099, device=dev, dtype=torch.float32) * (1.0 if rank == 0 else -1.0)
+            coll.broadcast(t, 0)
+            if not torch.equal(t.cpu(), torch.arange(4099, dtype=torch.float32)):
+                return "broadcast fp32 4099 elements from rank 0: wrong values"
+        with deadline.stage("selftest all_gather"):
+            mine = torch.full((1000,), float(rank), device=dev)
+            out = torch.empty(w * 1000, device=dev)
+            coll.all_gather(out, mine)
+            want = torch.arange(w, dtype=torch.float32).repeat_interleave(1000)
+            if not torch.equal(out.cpu(), want):
+                return "all_gather fp32 1000 elements per rank: wrong values"
+        with deadline.stage("selftest barrier"):
+            try:
+                coll.barrier(timeout_s=min(60.0, args.stage_timeout)) if hasattr(coll, "nranks") else coll.barrier()
+            except Exception as e:  # noqa: BLE001
+                return f"barrier: {type(e).__name__}: {e}"
+        return None
+
+    def run_eval(model):
+        """K forward-only steps in eval mode; the loss / correct@1 / correct@5 / row sums stay on the device and
+        cross the ranks in one fused all-reduce at the end."""
+        metrics = ops.new_metrics(dev)
+        model.eval()
+        with torch.no_grad():
+            for _ in range(min(3, args.eval_steps)):
+                ops.cross_entropy(model(images), target, metrics)
+            metrics.zero_()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.eval_steps):
+                ops.cross_entropy(model(images), target, metrics)
+            if "hvd" in hvd_info:
+                red = hvd_info["hvd"].allreduce(metrics, name="eval.metrics", op=hvd_info["hvd"].Sum)
+            elif world > 1:
+                red = pcomm.small_all_reduce(metrics.clone(), "sum")
+            else:
+                red = metrics
+            vals = [float(v) for v in red.tolist()]      # the one host read of the evaluation
+            fence()
+            dt = time.perf_counter() - t0
+        model.train()
+        rows = max(vals[3], 1.0)
+        return {"eval_images_per_sec": round(world * B * args.eval_steps / dt, 2), "eval_steps": args.eval_steps,
+                "eval_loss": round(vals[0] / rows, 4), "eval_acc1": round(vals[1] / rows, 4),
+                "eval_acc5": round(vals[2] / rows, 4), "eval_rows": int(vals[3]),
+                "eval_metric_allreduces": 1 if world > 1 else 0}
 
     def build_stock(channels_last: bool):
         model = models.torch_resnet(args.arch, args.num_classes).to(dev)
@@ -440,26 +596,86 @@ def worker(args) -> int:
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             return float(tmax.item()), float(loss.item())
 
-    model, step = build_native() if args.engine == "native" else build_stock(args.channels_last)
+    sweep = None
+
+    def buckets_of(m):
+        return [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
+                 "params": b["params"]} for b in m.bucket_summary()]
+
+    if args.engine == "native":
+        model, step = build_native(args.bucket_list[0])
+    elif args.engine == "hvd":
+        model, step = build_hvd()
+    else:
+        model, step = build_stock(args.channels_last)
+    if args.selftest and world > 1:
+        coll = comm_obj
+        if coll is None and args.engine == "stock":
+            from pytorch_distributed_amd.comm.rccl import TorchCollectives
+            coll = TorchCollectives()
+        if coll is None and args.engine == "hvd":
+            from pytorch_distributed_amd.hvd import mpi_ops as _M
+            coll = _M._device_coll(dev)
+        bad = selftest(coll) if coll is not None else "no data-plane communicator to test"
+        flag = torch.tensor([0 if bad is None else 1], dtype=torch.int32)
+        with deadline.stage("selftest vote"):
+            if dist.is_initialized():
+                dist.all_reduce(flag.to(dev) if dist.get_backend() == "nccl" else flag, op=dist.ReduceOp.MAX)
+        if bad is not None:
+            print(json.dumps({"error": f"rank {rank}: selftest failed: {bad}", "stage": "selftest", "rank": rank,
+                              "comm_backend": comm_info["comm_backend"]}), flush=True)
+            return 4
+        if int(flag.item()) != 0:
+            return 4
+        comm_info["selftest"] = "passed: all_reduce fp32/fp16 1KB/32MB, broadcast, all_gather, barrier"
     if ddp and args.engine == "native":
-        comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
-                                 "params": b["params"]} for b in model.bucket_summary()]
+        comm_info["buckets"] = buckets_of(model)
     graphed = False
     if args.graph and args.engine == "native" and not ddp:
         from pytorch_distributed_amd.utils.graph import GraphedStep
         step = GraphedStep(step, warmup=min(3, max(args.warmup, 1)))
         graphed = step.captured
+    elif args.graph and args.engine == "native" and ddp:
+        from pytorch_distributed_amd.utils.graph import GraphedStep
+        with deadline.stage("graph capture", factor=2.0):
+            step = GraphedStep(step, warmup=max(3, min(args.warmup, 6)), ddp=model)
+        graphed = step.captured
 
     dt, final_loss = timed(step)
-    if ddp and args.engine == "native":  # after the arrival-order rebuild
-        comm_info["buckets"] = [{"mb": round(b["bytes"] / 2 ** 20, 2), "wire_mb": round(b["wire_bytes"] / 2 ** 20, 2),
-                                 "params": b["params"]} for b in model.bucket_summary()]
     exposed = None
-    if ddp and args.engine == "native" and not on_cpu:
-        exposed = model.exposed_comm_ms(last=args.steps)
+    if ddp and args.engine == "native":
+        comm_info["buckets"] = buckets_of(model)      # after the arrival-order rebuild
+        if not on_cpu:
+            exposed = model.exposed_comm_ms(last=args.steps)
+    if ddp and args.engine == "native" and len(args.bucket_list) > 1:
+        # the other bucket sizes, same process, same communicator: the headline is the best of them
+        sweep = [{"bucket_mb": args.bucket_list[0], "ms_per_step": round(1000 * dt / args.steps, 3),
+                  "exposed_comm_ms_per_step": None if exposed is None else round(exposed, 3),
+                  "buckets": len(comm_info["buckets"])}]
+        best = (dt, final_loss, exposed, comm_info["buckets"], args.bucket_list[0])
+        import gc
+        for mb in args.bucket_list[1:]:
+            del model, step
+            gc.collect()
+            if not on_cpu:
+                torch.cuda.empty_cache()
+            model, step = build_native(mb)
+            dti, li = timed(step)
+            exi = model.exposed_comm_ms(last=args.steps) if not on_cpu else None
+            sweep.append({"bucket_mb": mb, "ms_per_step": round(1000 * dti / args.steps, 3),
+                          "exposed_comm_ms_per_step": None if exi is None else round(exi, 3),
+                          "buckets": len(model.bucket_summary())})
+            if dti < best[0]:
+                best = (dti, li, exi, buckets_of(model), mb)
+        dt, final_loss, exposed, comm_info["buckets"], comm_info["bucket_mb"] = best
+    eval_info = None
+    if args.eval_steps > 0 and args.engine in ("native", "hvd"):
+        with deadline.stage("evaluation", factor=2.0):
+            eval_info = run_eval(model)
     ips = world * B * args.steps / dt
     host_ms = 1000 * host_dt[0] / max(args.steps, 1)
     vs_stock = stock_ips = None
+    engine_stats = hvd_info["hvd"].engine_stats() if "hvd" in hvd_info else None
     if args.compare_stock and args.engine == "native" and not on_cpu:
         del model, step
         import gc
@@ -484,13 +700,15 @@ def worker(args) -> int:
             "config": {"model": args.arch, "global_batch": world * B, "per_gpu_batch": B, "image_size": S,
                        "seq_len": None, "parallelism": f"dp{world}", "engine": args.engine,
                        "amp_opt_level": args.opt_level if args.precision != "fp32" else "O0",
-                       "optimizer": "momentum-SGD (fused)" if args.engine == "native" else "torch.optim.SGD",
+                       "optimizer": ("momentum-SGD (fused)" if args.engine == "native" else
+                                     "hvd.DistributedOptimizer(momentum-SGD (fused))" if args.engine == "hvd" else
+                                     "torch.optim.SGD"),
                        "loss_scaling": "dynamic" if args.precision == "fp16" else "none",
                        "device": ("cpu (rehearsal, not a result)" if on_cpu else
                                   torch.cuda.get_device_name(dev) + (f" ({world} ranks sharing one GPU: rehearsal, "
                                                                      "not a result)" if share_gpu and world > 1 else "")),
                        "weights": "random-init",
-                       "conv_autotune": backends.benchmark if args.engine == "native" else None,
+                       "conv_autotune": backends.benchmark if args.engine in ("native", "hvd") else None,
                        "final_loss": round(final_loss, 4), "hip_graph": graphed, "cpu_binding": cpu_binding,
                        "host_issue_ms_per_step": round(host_ms, 3),
                        "exposed_comm_ms_per_step": None if exposed is None else round(exposed, 3),
@@ -498,13 +716,25 @@ def worker(args) -> int:
                        "wire_dtype": comm_info["wire_dtype"], "bucket_mb": comm_info["bucket_mb"],
                        "buckets": comm_info["buckets"],
                        "comm_fallback_reason": comm_info.get("comm_fallback_reason"),
+                       "selftest": comm_info.get("selftest"), "bucket_sweep": sweep,
+                       "sync_bn": bool(args.sync_bn), "hvd_engine_stats": engine_stats,
+                       "watchdog": watchdog is not None,
                        "stock_images_per_sec": (round(stock_ips, 2) if isinstance(stock_ips, float) else stock_ips),
                        "stock_comparator": ("same process, same model/batch/steps: torchvision-topology ResNet, "
                                             "channels_last, torch.autocast + GradScaler + torch.optim.SGD"
                                             if args.compare_stock else None),
                        "baseline_note": "reference publishes no number; vs_baseline is null"},
         }
+        if eval_info is not None:
+            out.update({"eval_images_per_sec": eval_info["eval_images_per_sec"]})
+            out["config"]["eval"] = eval_info
         print(json.dumps(out), flush=True)
+    if watchdog is not None:
+        from pytorch_distributed_amd.comm.watchdog import stop_watchdog
+        stop_watchdog()
+    if "hvd" in hvd_info:
+        with deadline.stage("hvd shutdown"):
+            hvd_info["hvd"].shutdown()
     if ddp:
         with deadline.stage("teardown"):
             pcomm.destroy_process_group()

@@ -34,10 +34,10 @@ _SIGS = {
     "pda_p2p_open_handle": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)],
     "pda_p2p_close_handle": [ctypes.c_void_p],
     "pda_p2p_allreduce": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_float, ctypes.c_void_p,
+                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                           ctypes.c_int, ctypes.c_void_p],
     "pda_p2p_allreduce_twoshot": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                  ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_uint,
+                                  ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,
                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
 }
 MAX_WORLD = 16
@@ -100,6 +100,9 @@ class _PeerRegion:
                 bases[p] = self._own.value
             self._bases = bases
             self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+            # {sequence number of the last call, workgroups of the running call that are done}: device memory, read
+            # and advanced by the kernels themselves, so a call recorded into a hipGraph stays in step on replay
+            self._seq_state = torch.zeros(2, dtype=torch.int32, device=self.device)
             if self.world_size > 1:
                 # nobody may push before every rank has mapped every region and nobody may free early:
                 # a second round of keys is the barrier
@@ -145,7 +148,6 @@ class P2PTwoShot(_PeerRegion):
                  cap_bytes: int = 32 << 20, key: str = "pda/p2p2", timeout_ms: int = 5000, group=None, nblk: int = 16):
         self.cap_bytes = int(cap_bytes) // 4096 * 4096
         self.timeout_ms, self.nblk = int(timeout_ms), int(nblk)
-        self._seq = 0
         l = _bind(_lib.lib())
         super().__init__(rank, world_size, int(l.pda_p2p2_region_bytes(self.cap_bytes)), store, device, key, group,
                          "P2PTwoShot")
@@ -169,11 +171,9 @@ class P2PTwoShot(_PeerRegion):
         m -= m % vec                                        # pieces stay 16-byte aligned
         for off in range(0, src.numel(), m):
             a, b = src[off:off + m], dst[off:off + m]
-            self._seq += 1
-            if self._seq >= 1 << 32:
-                self._seq = 1 + (self._seq & 1)   # keep the parity sequence, skip 0 (the flags' initial value)
             rc = self._l.pda_p2p_allreduce_twoshot(self._bases, _lib.dt(t), a.data_ptr(), b.data_ptr(), a.numel(),
-                                                   self.rank, self.world_size, self.cap_bytes, self._seq, scale,
+                                                   self.rank, self.world_size, self.cap_bytes,
+                                                   self._seq_state.data_ptr(), scale,
                                                    self._err.data_ptr(), self.timeout_ms, self.nblk, _lib.stream())
             _lib.check(rc, "pda_p2p_allreduce_twoshot")
         return out
@@ -192,7 +192,6 @@ class P2PAllReduce(_PeerRegion):
                  max_elems: int = 65536, key: str = "pda/p2p0", timeout_ms: int = 2000, group=None):
         self.max_elems = int(max_elems)
         self.timeout_ms = int(timeout_ms)
-        self._seq = 0
         nbytes = 2 * int(world_size) * self.max_elems * 4 + 2 * int(world_size) * 4
         nbytes = (nbytes + 4095) // 4096 * 4096
         super().__init__(rank, world_size, nbytes, store, device, key, group, "P2PAllReduce")
@@ -208,12 +207,10 @@ class P2PAllReduce(_PeerRegion):
         out = t if out is None else out
         if out.dtype != torch.float32 or out.numel() != t.numel() or not out.is_contiguous():
             raise TypeError("out must be a contiguous fp32 tensor of the same length")
-        self._seq += 1
-        if self._seq >= 1 << 32:
-            self._seq = 1 + (self._seq & 1)   # keep the parity sequence, skip 0 (the flags' initial value)
         scale = 1.0 / self.world_size if op == "avg" else 1.0
         rc = self._l.pda_p2p_allreduce(self._bases, t.data_ptr(), out.data_ptr(), t.numel(), self.rank,
-                                       self.world_size, self.max_elems, self._seq, scale, self._err.data_ptr(),
+                                       self.world_size, self.max_elems, self._seq_state.data_ptr(), scale,
+                                       self._err.data_ptr(),
                                        self.timeout_ms, _lib.stream())
         _lib.check(rc, "pda_p2p_allreduce")
         return out

@@ -30,17 +30,6 @@ _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3, to
 
 
 class _DoneWork:
-    def wait(self):
-        return True
-
-    def is_completed(self):
-        return True
-
-    def synchronize(self, timeout_s: float = 0.0):
-        return True
-
-
-class _DoneWork:
     """Work handle of a collective that had finished when the call returned."""
 
     def wait(self):

@@ -178,8 +178,15 @@ class Heartbeat:
                 return
             self._stop.wait(self.interval)
 
-    def stop(self):
+    def stop(self, finished: bool = True):
+        """``finished``: leave a beacon that never ages - a rank that ended its work in good order must not be
+        reported dead by peers that are still running."""
         self._stop.set()
+        if finished:
+            try:
+                self.store.set(f"hb/{self.rank}", str(time.time() + 1e9))
+            except Exception:
+                pass
 
     @staticmethod
     def dead_ranks(store, world_size: int, max_age: float = 10.0):

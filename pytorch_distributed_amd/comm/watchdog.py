@@ -77,10 +77,12 @@ class CommWatchdog:
                 finally:
                     return
 
-    def stop(self) -> None:
+    def stop(self, finished: bool = True) -> None:
+        """``finished=False``: stop beating without the "ended in good order" marker (tests use it to play a rank
+        that died)."""
         self._stop.set()
         if self._hb is not None:
-            self._hb.stop()
+            self._hb.stop(finished=finished)
         if self._t.is_alive() and threading.current_thread() is not self._t:
             self._t.join(timeout=2 * self.interval + 1)
 
@@ -90,3 +92,43 @@ class CommWatchdog:
     def __exit__(self, *exc):
         self.stop()
         return False
+
+
+_ACTIVE = {"wd": None}
+
+
+def start_watchdog(comm=None, interval: float = 1.0, max_age: Optional[float] = None,
+                   on_failure: Optional[Callable[[str], None]] = None) -> Optional[CommWatchdog]:
+    """Start (once per process) the monitor for the job the default process group describes: heartbeats through
+    the package's rendezvous store and, when there is one, the asynchronous error state of the device
+    communicator.  ``engine.fit``, the example scripts and the benchmark ranks call this right after the process
+    group exists; ``PDA_WATCHDOG=0`` turns it off, ``PDA_WATCHDOG_MAX_AGE`` sets the heartbeat age (seconds) after
+    which a silent peer counts as dead.  Returns None for single-process jobs or when no native store exists."""
+    if _ACTIVE["wd"] is not None:
+        return _ACTIVE["wd"]
+    if os.environ.get("PDA_WATCHDOG", "1") == "0":
+        return None
+    from . import native_store, rank_info, device_communicator, PrefixStore
+    info, st = rank_info(), native_store()
+    if info is None or info.world_size <= 1 or st is None:
+        return None
+    if comm is None:
+        try:
+            comm = device_communicator(create=False)
+        except Exception:  # noqa: BLE001
+            comm = None
+    if comm is not None and not hasattr(comm, "async_error"):
+        comm = None
+    if max_age is None:
+        max_age = float(os.environ.get("PDA_WATCHDOG_MAX_AGE", "30"))
+    _ACTIVE["wd"] = CommWatchdog(comm=comm, store=PrefixStore("watchdog", st), rank=info.rank,
+                                 world_size=info.world_size, interval=interval, max_age=max_age,
+                                 on_failure=on_failure)
+    return _ACTIVE["wd"]
+
+
+def stop_watchdog() -> None:
+    wd = _ACTIVE["wd"]
+    _ACTIVE["wd"] = None
+    if wd is not None:
+        wd.stop()

@@ -79,6 +79,9 @@ struct ConvArgs {
 // four classes, the classes of one tile position as neighbouring workgroups.
 enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_DGRAD_S2 = 2 };
 
+// s_waitcnt immediate (gfx9 layout): vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = do not wait), lgkmcnt 11:8
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8); }
+
 template <typename T> struct Mfma32;
 template <> struct Mfma32<f16> {
   typedef f16x8 frag;
@@ -780,16 +783,40 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[B][i], fb[B][j], acc[i][j]);
     };
+    auto group_next = [&](auto kk_, int ST) {  // group() of a step that is known not to be the last
+      constexpr int kk = decltype(kk_)::value, B = kk & 1;
+      if constexpr (kk + 1 < KK) fetch(std::integral_constant<int, B ^ 1>{}, ST, std::integral_constant<int, kk + 1>{});
+      else fetch(std::integral_constant<int, B ^ 1>{}, ST + 1 == STAGES ? 0 : ST + 1, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32<T>::run(fa[B][i], fb[B][j], acc[i][j]);
+      // (pinned on both sides: MFMAs touch no memory, so nothing else keeps the step's wait + barrier from being
+      // hoisted in among them, right behind the fragment reads it then has to wait for)
+      __builtin_amdgcn_sched_barrier(0);
+    };
     static_assert(KK % 2 == 0, "the fragment double buffer alternates per group");
     // One step = KK groups; the step's only barrier sits before the LAST group.  By then every read of tile
     // kt has been issued (the last group's fragments were prefetched during the group before) and, after the
     // lgkmcnt(0), has returned, so the barrier both publishes tile kt+1 (each wave waited for its own pieces)
     // and frees tile kt's buffer, into which tile kt+STAGES is requested at once: STAGES-1 tiles are in flight
     // while a step computes, with no more LDS than the ring itself.
+    // The waits are the builtin, not inline asm: the compiler's own wait-count pass reads a builtin s_waitcnt and
+    // knows that every fragment read has returned after it.  Behind an asm statement it assumed the reads of the
+    // step's first half were still pending and made the MFMAs after the barrier wait for the fragment reads of
+    // the NEXT tile that had just been issued (an `lgkmcnt(1)` four instructions after four ds_reads: one full LDS
+    // latency exposed per step).
     auto wait_keep = [&](int younger) {  // wave-uniform: tiles younger than the awaited one that may stay in flight
+#ifdef PDA_RING_LEGACY   // A/B build of the previous loop (python -m pytorch_distributed_amd._build --variant ringold PDA_RING_LEGACY)
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PIECES) : "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      return;
+#endif
+      if (younger >= 2) __builtin_amdgcn_s_waitcnt(waitcnt_imm(2 * PIECES, 0));
+      else if (younger == 1) __builtin_amdgcn_s_waitcnt(waitcnt_imm(PIECES, 0));
+      else __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
     };
     auto step = [&](int ST, int kt) {
       if (!PDA_ABL(2)) {
@@ -820,7 +847,29 @@ igemm_kernel(ConvArgs a) {
     PDA_STAMP(2);  // first tile staged
     if (nk > 0) fetch(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
     int st = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt = 0;
+    // steady state: a tile is requested in every step and STAGES - 2 younger ones stay in flight - the same
+    // straight-line code every time (no branch between the fragment reads and the MFMAs that the compiler
+    // would have to merge wait counts over)
+#ifndef PDA_RING_LEGACY
+    for (; kt < nk - STAGES; ++kt) {
+      if (!PDA_ABL(2)) {
+        group_next(std::integral_constant<int, 0>{}, st);
+        if constexpr (KK == 4) {
+          group_next(std::integral_constant<int, 1>{}, st);
+          group_next(std::integral_constant<int, 2>{}, st);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm((STAGES - 2) * PIECES, 0));
+      __builtin_amdgcn_s_barrier();
+      advance();
+      if (!PDA_ABL(1)) issue(st);
+      ++issued;
+      if (!PDA_ABL(2)) group_next(std::integral_constant<int, KK - 1>{}, st);
+      st = st + 1 == STAGES ? 0 : st + 1;
+    }
+#endif
+    for (; kt < nk; ++kt) {
       step(st, kt);
       st = st + 1 == STAGES ? 0 : st + 1;
     }

@@ -11,6 +11,9 @@
 // Two inbox/flag sets alternate with the parity of the sequence number: a rank can only enter call n+2
 // after every rank has pushed call n+1, which each of them does after finishing its own call n, so slot
 // set n%2 is never overwritten while somebody still reads it.
+// The sequence number lives in device memory (seq_state[0]; seq_state[1] counts the workgroups that are done):
+// every workgroup of a launch reads it, uses seq + 1, and the last one to finish stores the new value - so a
+// launch recorded into a hipGraph advances the protocol on every replay exactly as an eager launch does.
 // This is the latency path (metric scalars, SyncBatchNorm statistics, a few KB): a bandwidth-sized
 // reduction belongs to RCCL.  (Role in the reference: the NCCL all-reduce behind `dist.all_reduce` of
 // 0-dim metric tensors, /root/reference/2.distributed.py:71-75,219-223.)
@@ -29,10 +32,27 @@ struct P2PArgs {
   float scale;
   int n, rank, world, slot_elems;
   unsigned seq;
+  unsigned* seq_state;             // device memory of this rank: {sequence number of the last call, done counter}
 };
+
+// next sequence number after s: never 0 (the flags' initial value), parity alternates
+__device__ __forceinline__ unsigned p2p_next_seq(unsigned s) { return s == 0xffffffffu ? 2u : s + 1u; }
+
+// last workgroup of a launch to get here publishes the sequence number the launch used
+__device__ __forceinline__ void p2p_finish(unsigned* seq_state, unsigned seq) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(seq_state + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == gridDim.x - 1) {
+      __hip_atomic_store(seq_state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(seq_state, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 __global__ void __launch_bounds__(512) p2p_allreduce_oneshot_kernel(P2PArgs a) {
   const int t = threadIdx.x, nt = blockDim.x;
+  a.seq = p2p_next_seq(__hip_atomic_load(a.seq_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const int par = (int)(a.seq & 1u);
   const long long slot = (long long)(par * a.world + a.rank) * a.slot_elems;
   // 1. push (the own copy goes through the same path: slot [par][rank] of the own inbox)
@@ -64,6 +84,7 @@ __global__ void __launch_bounds__(512) p2p_allreduce_oneshot_kernel(P2PArgs a) {
     for (int p = 0; p < a.world; ++p) s += box[(long long)p * a.slot_elems + i];
     a.out[i] = s * a.scale;
   }
+  p2p_finish(a.seq_state, a.seq);
 }
 
 static int p2p_err(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
@@ -100,9 +121,10 @@ PDA_EXPORT int pda_p2p_close_handle(void* ptr) { return p2p_err(hipIpcCloseMemHa
 // bases[p]: the region of rank p as mapped into this process (own region for p == rank).
 // Region layout: [2][world][slot_elems] floats, then [2][world] unsigned flags.
 PDA_EXPORT int pda_p2p_allreduce(void* const* bases, const float* in, float* out, int n, int rank, int world,
-                                 int slot_elems, unsigned seq, float scale, int* err, int timeout_ms,
+                                 int slot_elems, unsigned* seq_state, float scale, int* err, int timeout_ms,
                                  hipStream_t st) {
-  if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world || n < 0 || n > slot_elems || seq == 0)
+  if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world || n < 0 || n > slot_elems ||
+      seq_state == nullptr)
     return -1;
   if (n == 0) return 0;
   P2PArgs a;
@@ -113,7 +135,8 @@ PDA_EXPORT int pda_p2p_allreduce(void* const* bases, const float* in, float* out
   }
   a.in = in; a.out = out; a.err = err;
   a.timeout_ticks = (long long)timeout_ms * 100000LL;
-  a.scale = scale; a.n = n; a.rank = rank; a.world = world; a.slot_elems = slot_elems; a.seq = seq;
+  a.scale = scale; a.n = n; a.rank = rank; a.world = world; a.slot_elems = slot_elems; a.seq = 0;
+  a.seq_state = seq_state;
   const int threads = n >= 512 ? 512 : (n > 64 ? ((n + 63) / 64) * 64 : 64);
   hipLaunchKernelGGL(p2p_allreduce_oneshot_kernel, dim3(1), dim3(threads), 0, st, a);
   return pda_check_launch();
@@ -154,6 +177,7 @@ struct P2P2Args {
   float scale;
   int rank, world;
   unsigned seq;
+  unsigned* seq_state;             // as in P2PArgs
 };
 
 template <typename T> struct P2P2Layout {
@@ -205,6 +229,7 @@ template <typename T>
 __global__ void __launch_bounds__(512) p2p_allreduce_twoshot_kernel(P2P2Args a) {
   constexpr int V = 16 / sizeof(T);
   const int t = threadIdx.x, nt = blockDim.x, blk = blockIdx.x;
+  a.seq = p2p_next_seq(__hip_atomic_load(a.seq_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   const int par = (int)(a.seq & 1u);
   const T* __restrict__ in = static_cast<const T*>(a.in);
   T* __restrict__ out = static_cast<T*>(a.out);
@@ -264,6 +289,7 @@ __global__ void __launch_bounds__(512) p2p_allreduce_twoshot_kernel(P2P2Args a) 
     const long long len = slice_len(j);
     if (len > 0) p2p2_copy<T>(out + (long long)j * a.shard + s0, res + (long long)j * a.shard + s0, len, t, nt);
   }
+  p2p_finish(a.seq_state, a.seq);
 }
 
 // Bytes of one rank's region for messages of up to cap_bytes.
@@ -275,10 +301,10 @@ PDA_EXPORT long long pda_p2p2_region_bytes(long long cap_bytes) {
 // bases[p]: region of rank p (pda_p2p2_region_bytes(cap_bytes) each, zero-initialised).  dtype: 0 fp32, 1 fp16,
 // 2 bf16.  n * sizeof(T) <= cap_bytes; in/out 16-byte aligned; nblk workgroups (1..64).
 PDA_EXPORT int pda_p2p_allreduce_twoshot(void* const* bases, int dtype, const void* in, void* out, long long n,
-                                         int rank, int world, long long cap_bytes, unsigned seq, float scale, int* err,
-                                         int timeout_ms, int nblk, hipStream_t st) {
+                                         int rank, int world, long long cap_bytes, unsigned* seq_state, float scale,
+                                         int* err, int timeout_ms, int nblk, hipStream_t st) {
   const int esz = dtype == PDA_F32 ? 4 : 2;
-  if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world || n < 0 || seq == 0 || nblk < 1 ||
+  if (world < 1 || world > P2P_MAX_WORLD || rank < 0 || rank >= world || n < 0 || seq_state == nullptr || nblk < 1 ||
       nblk > P2P2_MAX_BLOCKS || dtype < 0 || dtype > 2 || n * esz > cap_bytes || cap_bytes % 16 != 0)
     return -1;
   if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) return -2;
@@ -291,7 +317,8 @@ PDA_EXPORT int pda_p2p_allreduce_twoshot(void* const* bases, int dtype, const vo
   a.n = n; a.cap = cap_bytes / esz;
   a.shard = ((n + world - 1) / world + V - 1) / V * V;
   a.slice = ((a.shard + nblk - 1) / nblk + V - 1) / V * V;
-  a.scale = scale; a.rank = rank; a.world = world; a.seq = seq;
+  a.scale = scale; a.rank = rank; a.world = world; a.seq = 0;
+  a.seq_state = seq_state;
   if (a.shard * world > a.cap) return -3;   // the rounded-up shards must still fit the inbox slots
 #define L_P2P2(T) hipLaunchKernelGGL((p2p_allreduce_twoshot_kernel<T>), dim3(nblk), dim3(512), 0, st, a)
   if (dtype == PDA_F32) L_P2P2(float);

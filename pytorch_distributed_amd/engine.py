@@ -287,6 +287,23 @@ def fit(args, model, optimizer, device, train_set, val_set, per_rank_batch: int,
         return validate(val_loader, model, criterion, device, args, val_sampler)
     csv = utils.EpochCSV(csv_path) if (csv_path and chief) else None
     jsonl = utils.JsonlLogger(args.jsonl) if args.jsonl else None
+    # failure detection for the whole run: a rank that dies (or a link that goes away under a collective) ends
+    # the job with a non-zero exit code instead of leaving the others inside their next all-reduce, which is what
+    # happens to the reference's loop (/root/reference/2.distributed.py:219-223)
+    from .comm.watchdog import start_watchdog, stop_watchdog
+    if distributed:
+        start_watchdog()
+    try:
+        best_acc1 = _fit_epochs(args, model, optimizer, device, criterion, train_loader, val_loader, train_sampler,
+                                val_sampler, prefetch_norm, pin, zero_grad, csv, jsonl, chief, best_acc1,
+                                save_prefix_arch)
+    finally:
+        stop_watchdog()
+    return best_acc1
+
+
+def _fit_epochs(args, model, optimizer, device, criterion, train_loader, val_loader, train_sampler, val_sampler,
+                prefetch_norm, pin, zero_grad, csv, jsonl, chief, best_acc1, save_prefix_arch):
     for epoch in range(args.start_epoch, args.epochs):
         t0 = time.time()
         if train_sampler is not None:

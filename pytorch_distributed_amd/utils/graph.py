@@ -14,9 +14,17 @@ replayed with a single launch per iteration.
         loss = step()          # replays forward + backward + optimizer update
 
 Constraints (those of stream capture): fixed shapes, inputs in fixed buffers, single device, no
-collectives inside the captured region (use it for single-GPU runs), no ``.item()`` / printing of
-device values inside ``fn``.  Values returned by ``fn`` are static tensors that are overwritten by
-every replay.
+``.item()`` / printing of device values inside ``fn``.  Values returned by ``fn`` are static tensors that
+are overwritten by every replay.
+
+A step under ``DistributedDataParallel`` records as well (pass the wrapper as ``ddp=``): the bucket pack, the
+all-reduce and the hand-over to the fused optimizer are stream work - the RCCL call on the communicator's own
+stream joins the capture through the event the wrapper records behind the bucket's last gradient, and the
+peer-memory kernels keep their sequence numbers in device memory - so every replay runs the same collectives
+in the same order on every rank.  The eager warm-up has to cover the one-time bucket rebuild (two steps);
+the exposed-communication probe is switched off because its timing events cannot live inside a graph.  The
+Horovod-style engine cannot be recorded (its collectives are launched from a thread of its own, when the
+negotiation completes).
 """
 from __future__ import annotations
 
@@ -29,8 +37,12 @@ class GraphedStep:
     """Capture ``fn()`` after ``warmup`` eager runs; calling the object replays the graph."""
 
     def __init__(self, fn: Callable[[], Any], warmup: int = 3, device: Optional[torch.device] = None,
-                 enabled: bool = True):
+                 enabled: bool = True, ddp=None):
         self._fn = fn
+        if ddp is not None:
+            warmup = max(int(warmup), 2)
+            if getattr(ddp, "_exposed_probe", None) is not None:
+                ddp.measure_exposed_comm(False)
         self._graph = None
         self._out = None
         self.enabled = bool(enabled) and torch.cuda.is_available()
@@ -45,6 +57,9 @@ class GraphedStep:
             for _ in range(max(int(warmup), 0)):  # 0: the caller has already run the step eagerly
                 fn()
         self._stream.synchronize()
+        if ddp is not None and getattr(ddp, "_rebuild_pending", False):
+            raise RuntimeError("GraphedStep: the DistributedDataParallel wrapper has not rebuilt its buckets yet "
+                               "(the warm-up steps must run a backward pass)")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=self._stream):
             self._out = fn()

@@ -78,3 +78,40 @@ def test_bench_stage_deadline_reports_instead_of_hanging_cpu():
     assert r.returncode != 0
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines and "error" in json.loads(lines[-1])
+
+
+def _bench(extra, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PDA_BENCH_DEVICE="cpu", OMP_NUM_THREADS="2")
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"] + _SMALL + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_bench_hvd_engine_with_eval_two_ranks_cpu():
+    """--engine hvd: hvd.init / broadcast_parameters / broadcast_optimizer_state / DistributedOptimizer with fp16
+    compression + SyncBatchNorm, then the forward-only evaluation whose metric sums cross the ranks in ONE
+    all-reduce (BASELINE config 5's shape), under the same supervisor."""
+    r, lines = _bench(["--engine", "hvd", "--precision", "fp16", "--sync-bn", "--eval-steps", "2"])
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["engine"] == "hvd" and cfg["sync_bn"] is True
+    assert cfg["hvd_engine_stats"]["fused_groups"] > 0 and "hvd" in cfg["optimizer"]
+    assert out["eval_images_per_sec"] > 0 and cfg["eval"]["eval_rows"] == 2 * 2 * 2
+    assert cfg["eval"]["eval_metric_allreduces"] == 1 and 0.0 <= cfg["eval"]["eval_acc1"] <= 1.0
+
+
+def test_bench_selftest_and_bucket_sweep_cpu():
+    r, lines = _bench(["--selftest", "--bucket-mb", "1,4,25", "--precision", "fp32"],
+                      env_extra={"PDA_BENCH_WATCHDOG": "1"})
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1000:], r.stderr[-3000:])
+    cfg = json.loads(lines[0])["config"]
+    assert cfg["selftest"].startswith("passed") and cfg["watchdog"] is True
+    sweep = cfg["bucket_sweep"]
+    assert [s["bucket_mb"] for s in sweep] == [1.0, 4.0, 25.0] and all(s["ms_per_step"] > 0 for s in sweep)
+    assert cfg["bucket_mb"] in (1.0, 4.0, 25.0)
+    assert json.loads(lines[0])["ms_per_step"] == min(s["ms_per_step"] for s in sweep)
+    assert sweep[0]["buckets"] > sweep[2]["buckets"]

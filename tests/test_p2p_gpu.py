@@ -146,6 +146,14 @@ def test_overflow_check_stores_nothing():
         assert all(bool((d == 7.0).all()) for d in dst) and int(flag) == 1
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_graphed_ddp_step_matches_eager(world):
+    """The DistributedDataParallel step (bucket pack, all-reduce on the communicator's stream, fused-wire SGD,
+    side-stream weight gradients) recorded into a hipGraph and replayed == the eager step, bit for bit.  One rank
+    on the own RCCL communicator; two ranks sharing the GPU on the peer-memory two-shot kernel."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "ddp_graph_worker.py"), world)
+
+
 def test_bench_supervisor_with_two_ranks_sharing_the_gpu():
     """``python bench.py --gpus 2`` end to end on the one-GPU box: the supervisor starts two ranks through the
     package's launcher, both use GPU 0 (PDA_BENCH_SHARE_GPU=1) and reduce their buckets through the peer-memory
