@@ -398,7 +398,8 @@ def worker(args) -> int:
                 kind = make_native_comm()
             with deadline.stage("parameter broadcast"):
                 model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=bucket_mb,
-                            force_comm=args.force_ddp, comm=kind, wire_dtype=args.wire_dtype)
+                            force_comm=args.force_ddp, comm=kind, wire_dtype=args.wire_dtype,
+                            fused_wire=True)   # nothing here reads param.grad between backward and step
                 comm_obj = model._coll
                 if not on_cpu:
                     model.measure_exposed_comm(True)
@@ -427,6 +428,9 @@ def worker(args) -> int:
     def build_hvd():
         """The loop of /root/reference/5.horovod_distributed.py:116-125,219-221 on this package's hvd module."""
         nonlocal comm_obj
+        if share_gpu and world > 1:
+            # ranks sharing one GPU: the engine's device collectives go through the peer-memory backend
+            os.environ.update(PDA_HVD_DEVICE_COMM="p2p", PDA_HVD_P2P_DEVICE="0", PDA_HVD_NO_CUDA="1")
         import pytorch_distributed_amd.hvd as hvd
         with deadline.stage("hvd.init"):
             hvd.init()

@@ -158,10 +158,7 @@ class C10dStoreAdapter(dist.Store):
         return True
 
     def append(self, key, value):
-        # (no atomic append in the native protocol: the c10d users of it - flight-recorder dumps, barrier lists -
-        # tolerate a read-modify-write between cooperating ranks that write distinct keys)
-        old = self._n.get(key, 0.0) if self._n.check([key]) else b""
-        self._n.set(key, bytes(old) + (value if isinstance(value, (bytes, bytearray)) else str(value).encode()))
+        self._n.append(key, value if isinstance(value, (bytes, bytearray)) else str(value).encode())
 
     def multi_get(self, keys):
         return [self.get(k) for k in keys]

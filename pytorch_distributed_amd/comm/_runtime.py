@@ -25,6 +25,7 @@ _SIGS = {
     "pda_store_delete": (c_i, [c_p, c_cp]),
     "pda_store_num_keys": (c_ll, [c_p]),
     "pda_store_compare_set": (c_ll, [c_p, c_cp, c_cp, c_i, c_cp, c_i, c_p, c_ll]),
+    "pda_store_append": (c_ll, [c_p, c_cp, c_cp, c_i]),
     "pda_shm_create": (c_p, [c_cp, c_i, c_i, c_ll, c_ll]),
     "pda_shm_destroy": (None, [c_p]),
     "pda_shm_all_reduce_async": (c_ll, [c_p, c_p, c_ll, c_i, c_i]),

@@ -307,6 +307,15 @@ class P2PCollectives:
             if self.rank != src:
                 t.zero_()
             self._device_all_reduce(t, "sum")   # everybody but src contributes zeros
+        elif t.is_cuda and not t.dtype.is_floating_point and not t.dtype.is_complex:
+            # integer buffers (BatchNorm's num_batches_tracked) stay on the device too, so that a training step
+            # can be recorded into a hipGraph: every byte becomes one fp32 value (exact), the all-reduce adds
+            # zeros to it (exact), and the bytes are put back
+            b = t.contiguous().reshape(-1).view(torch.uint8).to(torch.float32)
+            if self.rank != src:
+                b.zero_()
+            self._device_all_reduce(b, "sum")
+            t.copy_(b.to(torch.uint8).view(t.dtype).reshape(t.shape))
         else:
             self._host(t, lambda c: self._dist.broadcast(c, src=src, group=self.group))
         return _Done() if async_op else None

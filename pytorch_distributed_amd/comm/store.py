@@ -89,6 +89,15 @@ class Store:
     def num_keys(self) -> int:
         return int(self._l.pda_store_num_keys(self._h))
 
+    def append(self, key: str, value: Union[str, bytes]) -> int:
+        """value(key) += value as ONE operation on the server (or under the file lock): concurrent appenders to
+        one key lose nothing.  Returns the new length."""
+        v = _b(value)
+        n = self._l.pda_store_append(self._h, key.encode(), v, len(v))
+        if n < 0:
+            raise RuntimeError(f"store.append({key!r}) failed")
+        return int(n)
+
     def compare_set(self, key: str, expected: Union[str, bytes], desired: Union[str, bytes]) -> bytes:
         e, d = _b(expected), _b(desired)
         cap = max(4096, len(d) + 16)
@@ -146,6 +155,9 @@ class PrefixStore:
 
     def compare_set(self, key, expected, desired):
         return self.store.compare_set(self._k(key), expected, desired)
+
+    def append(self, key, value):
+        return self.store.append(self._k(key), value)
 
     def num_keys(self):
         return self.store.num_keys()

@@ -39,7 +39,8 @@
 
 namespace {
 
-enum Op : uint8_t { OP_SET = 1, OP_GET = 2, OP_ADD = 3, OP_CHECK = 4, OP_DELETE = 5, OP_NUMKEYS = 6, OP_CAS = 7 };
+enum Op : uint8_t { OP_SET = 1, OP_GET = 2, OP_ADD = 3, OP_CHECK = 4, OP_DELETE = 5, OP_NUMKEYS = 6, OP_CAS = 7,
+                    OP_APPEND = 8 };  // value = value + bytes, in one step on the server (c10d Store::append)
 
 using Clock = std::chrono::steady_clock;
 
@@ -181,6 +182,16 @@ class TcpServer {
         consumed = need + 4 + vlen;
         reply_i64(c.fd, 0);
         key_arrived(key);
+      } else if (op == OP_APPEND) {
+        if (b.size() < need + 4) return;
+        uint32_t vlen;
+        memcpy(&vlen, b.data() + need, 4);
+        if (b.size() < need + 4 + vlen) return;
+        std::string& cur = kv_[key];
+        cur.append(b, need + 4, vlen);
+        consumed = need + 4 + vlen;
+        reply_i64(c.fd, (int64_t)cur.size());
+        key_arrived(key);
       } else if (op == OP_GET) {
         if (b.size() < need + 8) return;
         int64_t tmo;
@@ -310,6 +321,7 @@ class Store {
   virtual int del(const std::string& k) = 0;
   virtual int64_t num_keys() = 0;
   virtual int cas(const std::string& k, const std::string& expect, const std::string& desired, std::string* out) = 0;
+  virtual int64_t append(const std::string& k, const std::string& v) = 0;  // new length of the value, <0 error
 };
 
 class TcpStore : public Store {
@@ -374,6 +386,14 @@ class TcpStore : public Store {
     std::lock_guard<std::mutex> g(mu_);
     std::string m = head(OP_NUMKEYS, "");
     int64_t r = 0;
+    if (xfer_i64(m, &r) != 0) return -1;
+    return r;
+  }
+  int64_t append(const std::string& k, const std::string& v) override {
+    std::lock_guard<std::mutex> g(mu_);
+    std::string m = head(OP_APPEND, k);
+    put_str(m, v);
+    int64_t r = -1;
     if (xfer_i64(m, &r) != 0) return -1;
     return r;
   }
@@ -513,6 +533,14 @@ class FileStore : public Store {
     refresh();
     return (int64_t)kv_.size();
   }
+  int64_t append(const std::string& k, const std::string& v) override {
+    Lock l(fd_);   // read-modify-write under the file lock: atomic across processes
+    refresh();
+    auto it = kv_.find(k);
+    const std::string joined = (it != kv_.end() ? it->second : std::string()) + v;
+    append('S', k, joined);
+    return (int64_t)joined.size();
+  }
   int cas(const std::string& k, const std::string& expect, const std::string& desired, std::string* out) override {
     Lock l(fd_);
     refresh();
@@ -624,6 +652,9 @@ PDA_EXPORT int pda_store_add(void* h, const char* key, long long delta, long lon
 PDA_EXPORT int pda_store_check(void* h, const char* key) { return static_cast<Store*>(h)->check(key); }
 PDA_EXPORT int pda_store_delete(void* h, const char* key) { return static_cast<Store*>(h)->del(key); }
 PDA_EXPORT long long pda_store_num_keys(void* h) { return static_cast<Store*>(h)->num_keys(); }
+PDA_EXPORT long long pda_store_append(void* h, const char* key, const void* val, int len) {
+  return static_cast<Store*>(h)->append(key, std::string(static_cast<const char*>(val), (size_t)len));
+}
 PDA_EXPORT long long pda_store_compare_set(void* h, const char* key, const void* expect, int elen, const void* desired,
                                            int dlen, void* out, long long cap) {
   std::string v;

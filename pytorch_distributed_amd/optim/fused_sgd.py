@@ -197,6 +197,10 @@ class FusedSGD(Optimizer):
                     self._lists[ck] = tl
                 mt.sgd(tl, self._group_hp(gi, group, plist[0].device), first_run=fresh, dev_scale=dev_scale,
                        noop_flag=noop, grad_scale=key[3])
+        for group in self.param_groups:   # a wire-bucket hand-over is good for one update
+            for p in group["params"]:
+                if getattr(p, "_pda_wire_grad", None) is not None:
+                    p._pda_wire_grad = None
         bump_param_generation(self._model_copies.values())
         if scaler is not None and scaler.enabled:
             scaler.after_step()

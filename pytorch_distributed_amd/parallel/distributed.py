@@ -25,10 +25,13 @@ and from ``apex.parallel.DistributedDataParallel(model)``
   O1-O3, else the gradient dtype) halves the bytes on the links - the Horovod ``Compression.fp16`` idea
   (/root/reference/5.horovod_distributed.py:123).  A ready bucket is cast into its persistent wire
   buffer by ONE multi-tensor launch that also applies the pre-division (1/world for fp16 so the sum
-  cannot leave the fp16 range) and flags overflow; a fused optimizer (``optim.FusedSGD``) then reads the
-  all-reduced wire buffer directly, with the remaining 1/world folded into its update kernel, so the
-  reduced gradient is never cast back (``fused_wire``); any other optimizer gets it unpacked into
-  ``param.grad`` by one launch per bucket;
+  cannot leave the fp16 range) and flags overflow; after the all-reduce one launch per bucket unpacks the
+  reduced gradient into ``param.grad`` - which therefore holds the averaged gradient after backward, as it
+  does under torch's and apex's wrappers (clipping, logging and any optimizer see the same thing).  With
+  ``fused_wire=True`` (opt-in; env ``PDA_DDP_FUSED_WIRE=1``) a fused optimizer (``optim.FusedSGD``) reads the
+  all-reduced wire buffer directly instead, with the remaining 1/world folded into its update kernel, and the
+  unpack pass is skipped: ``param.grad`` then keeps the LOCAL gradient, and code between backward and step
+  has to go through ``reduced_grad()`` / ``clip_grad_norm_()`` of this wrapper;
 * after the first backward the plan is rebuilt in gradient-arrival order (rank 0's
   order is broadcast so every rank rebuilds identically);
 * module buffers (BatchNorm running stats) are re-broadcast from rank 0 before each
@@ -164,10 +167,12 @@ class DistributedDataParallel(nn.Module):
         self._pre = self.predivide
         if wire_dtype == torch.float16 and self.predivide == 1.0 and gradient_average:
             self._pre = float(self.world_size)
-        # fused_wire: None = on as soon as a fused optimizer announces itself (FusedSGD does, whether it
-        # is built before or after this wrapper), False = always unpack into param.grad
-        self._fused_wire_allowed = fused_wire is not False
-        self.fused_wire = bool(fused_wire) and wire_dtype is not None
+        # fused_wire (opt-in): the hand-over starts as soon as a fused optimizer announces itself (FusedSGD does,
+        # whether it is built before or after this wrapper); default: always unpack into param.grad
+        if fused_wire is None:
+            fused_wire = os.environ.get("PDA_DDP_FUSED_WIRE", "0") == "1"
+        self._fused_wire_allowed = bool(fused_wire)
+        self.fused_wire = False
         # SUM + one scale pass by default; RCCL's AVG op saves that pass but is opt-in (use_avg_op)
         self._use_avg_op = (use_avg_op and self._on_device and gradient_average and self.predivide == 1.0
                             and wire_dtype is None)
@@ -475,8 +480,34 @@ class DistributedDataParallel(nn.Module):
             return w[0].float() * w[1]
         return param.grad
 
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm: float, eps: float = 1e-6) -> torch.Tensor:
+        """``torch.nn.utils.clip_grad_norm_`` over the REDUCED gradients, wherever they live (``param.grad``, or
+        the wire buckets in fused-wire mode, whose pending 1/world factor is accounted for).  No host
+        synchronisation: the norm and the clip coefficient stay on the device.  Returns the total norm."""
+        plain, wired = [], {}
+        for p in self._params:
+            w = getattr(p, "_pda_wire_grad", None)
+            if w is not None:
+                wired.setdefault(float(w[1]), []).append(w[0])
+            elif p.grad is not None:
+                plain.append(p.grad)
+        sq = []
+        if plain:
+            sq.append(mt.l2norm(mt.TensorLists([[_physical_flat(g) for g in plain]]))[0].float() ** 2)
+        for post, gs in wired.items():
+            sq.append((mt.l2norm(mt.TensorLists([[_physical_flat(g) for g in gs]]))[0].float() * post) ** 2)
+        total = torch.sqrt(torch.stack(sq).sum()) if sq else torch.zeros((), device=self.device)
+        coef = torch.clamp(max_norm / (total + eps), max=1.0)
+        for gs in [plain] + list(wired.values()):
+            for dt in {g.dtype for g in gs}:
+                torch._foreach_mul_([g for g in gs if g.dtype == dt], coef.to(dt))
+        return total
+
     def zero_grad(self, set_to_none: bool = False) -> None:
         """One memset per bucket; keeps ``param.grad`` pointing into the buckets."""
+        if self.fused_wire:
+            self._drop_wire_handover()   # a step() without a backward in between must not reuse old wire gradients
         for bk in self._buckets:
             bk.flat.zero_()
         for bk in self._buckets:

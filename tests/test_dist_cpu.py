@@ -126,6 +126,10 @@ def test_ddp_matches_averaged_single_process_grads(wire):
     spawn(W.ddp_equivalence, args=(2, free_port(), wire), nprocs=2)
 
 
+def test_ddp_param_grad_is_the_reduced_gradient_by_default():
+    spawn(W.ddp_grad_semantics, args=(2, free_port()), nprocs=2)
+
+
 def test_apex_flavoured_ddp():
     spawn(W.apex_flavour, args=(2, free_port()), nprocs=2)
 
@@ -155,3 +159,39 @@ def test_hvd_with_amp_skips_overflowed_step_on_every_rank(kind):
                         kind], cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("hvd amp OK") == 2
+
+
+def _append_records(i, per, kind, arg):
+    st = TCPStore("127.0.0.1", arg, 1, is_master=False, timeout=20) if kind == "tcp" else FileStore(arg, 1, timeout=20)
+    for j in range(per):
+        st.append("log", f"{i}:{j};")
+    st.close()
+
+
+def test_store_append_is_atomic(tmp_path):
+    """Eight writers append to ONE key through their own connections: every record arrives, each writer's in
+    order (the c10d adapter's append used to be a read-modify-write that lost concurrent writes).  TCP store:
+    threads; file store: processes (its lock is a per-process fcntl lock)."""
+    import multiprocessing as mp
+    master = TCPStore("127.0.0.1", 0, 1, is_master=True, timeout=20)
+    fpath = str(tmp_path / "fstore")
+    n, per = 8, 100
+    ts = [threading.Thread(target=_append_records, args=(i, per, "tcp", master.port)) for i in range(n)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    ctx = mp.get_context("fork")
+    ps = [ctx.Process(target=_append_records, args=(i, per, "file", fpath)) for i in range(n)]
+    [p.start() for p in ps]
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    for reader in (TCPStore("127.0.0.1", master.port, 1, is_master=False, timeout=20), FileStore(fpath, 1, timeout=20)):
+        recs = [r for r in reader.get("log").decode().split(";") if r]
+        reader.close()
+        assert len(recs) == n * per and len(set(recs)) == n * per
+        for i in range(n):
+            assert [int(r.split(":")[1]) for r in recs if r.startswith(f"{i}:")] == list(range(per))
+    ad = comm.C10dStoreAdapter(PrefixStore("c", master))
+    ad.append("k", b"ab")
+    ad.append("k", "cd")
+    assert bytes(ad.get("k")) == b"abcd"
+    master.close()

@@ -42,7 +42,7 @@ def _run_ranks(worker, world, attempts=3, extra=()):
             continue
         break
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {r}: OK" in o, (r, o[-2000:])
+        assert p.returncode == 0 and f"rank {r}: OK" in o, (r, o[-6000:])
 
 
 def _start_ranks(worker, world, extra=()):

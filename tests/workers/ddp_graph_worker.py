@@ -27,10 +27,10 @@ def build(dev, rank, world, tag):
     m, opt = amp.initialize(m, opt, opt_level="O2", loss_scale=128.0, verbosity=0)
     if world > 1:
         coll = P2PCollectives(rank, world, store=comm.PrefixStore(tag, comm.native_store()), device=dev, overlap=True)
-        ddp = DDP(m, device_ids=[0], bucket_cap_mb=8, comm=coll)
+        ddp = DDP(m, device_ids=[0], bucket_cap_mb=8, comm=coll, fused_wire=True)
     else:
         coll = None
-        ddp = DDP(m, device_ids=[0], bucket_cap_mb=8, force_comm=True)      # own RCCL communicator, one rank
+        ddp = DDP(m, device_ids=[0], bucket_cap_mb=8, force_comm=True, fused_wire=True)      # own RCCL communicator, one rank
     assert ddp.wire_dtype == torch.float16 and ddp.fused_wire
     return m, opt, ddp, coll
 

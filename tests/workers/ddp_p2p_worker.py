@@ -60,11 +60,13 @@ def main():
                 p.add_(0.5)
     overlap = os.environ.get("PDA_TEST_OVERLAP", "1" if MODE == "O2" else "0") == "1"
     wire = os.environ.get("PDA_TEST_WIRE", "auto")
-    fused = {"1": True, "0": False}.get(os.environ.get("PDA_TEST_FUSED", ""), None)
+    # (the hand-over of the wire buckets to the fused optimizer is opt-in: O2 mode asks for it, O0 mode leaves the
+    # default - reduced gradients unpacked into param.grad)
+    fused = {"1": True, "0": False}.get(os.environ.get("PDA_TEST_FUSED", ""), True if MODE == "O2" else None)
     coll = P2PCollectives(rank, world, store=comm.PrefixStore("ddpc", comm.native_store()), device=dev,
                           overlap=overlap)
     ddp = DDP(net, device_ids=[0], bucket_cap_mb=8, comm=coll, wire_dtype=wire, fused_wire=fused)
-    if MODE == "O2" and wire == "auto" and fused is None:
+    if MODE == "O2" and wire == "auto" and fused is True:
         assert ddp.wire_dtype == torch.float16 and ddp.fused_wire, (ddp.wire_dtype, ddp.fused_wire)
     twin = twin_opt = None
     if MODE == "O2":

@@ -146,3 +146,58 @@ def crasher(rank, marker):
         raise ValueError("boom from rank 1")
     time.sleep(60)
     open(marker, "w").write("survived")
+
+
+def ddp_grad_semantics(rank, world, port):
+    """param.grad is the AVERAGED gradient after backward by default, also next to a fused optimizer and a 16-bit
+    wire; with fused_wire=True the reduced gradient lives in the wire buckets (reduced_grad / clip_grad_norm_ find
+    it there) and the hand-over does not outlive zero_grad() or step()."""
+    _init(rank, world, port)
+    from pytorch_distributed_amd import models, ops
+    from pytorch_distributed_amd.optim import FusedSGD
+    from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
+    torch.manual_seed(100)
+    X, T = torch.randn(4 * world, 3, 32, 32), torch.randint(0, 10, (4 * world,))
+    x, t = X[rank * 4:(rank + 1) * 4], T[rank * 4:(rank + 1) * 4]
+    for fused in (None, True):
+        torch.manual_seed(7)
+        net = models.resnet18(num_classes=10)
+        opt = FusedSGD(net.parameters(), lr=0.1, momentum=0.0)
+        ddp = DDP(net, bucket_cap_mb=4, wire_dtype=torch.bfloat16, fused_wire=fused)
+        assert ddp.fused_wire == bool(fused)
+        ref = models.resnet18(num_classes=10)
+        ref.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+        ddp.zero_grad()
+        ops.cross_entropy(ddp(x), t).backward()
+        acc = None                                       # average of the ranks' gradients (BatchNorm per shard)
+        for r in range(world):
+            ref.zero_grad()
+            ops.cross_entropy(ref(X[r * 4:(r + 1) * 4]), T[r * 4:(r + 1) * 4]).backward()
+            gs = [p.grad.clone() for p in ref.parameters()]
+            acc = gs if acc is None else [a + g for a, g in zip(acc, gs)]
+        for p, a in zip(ref.parameters(), acc):
+            p.grad = a / world
+        ps, rs = list(net.parameters()), list(ref.parameters())
+        big = max(range(len(ps)), key=lambda i: ps[i].numel())
+        rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+        assert rel(ddp.reduced_grad(ps[big]), rs[big].grad) < 2e-2
+        if fused:
+            assert getattr(ps[big], "_pda_wire_grad", None) is not None
+            assert rel(ps[big].grad, rs[big].grad) > 1e-3     # local gradient: another batch
+        else:
+            assert getattr(ps[big], "_pda_wire_grad", None) is None
+            assert rel(ps[big].grad, rs[big].grad) < 2e-2      # what clipping / logging code reads
+        ref_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        norm = ddp.clip_grad_norm_(0.5)
+        assert abs(float(norm) - float(ref_norm)) / float(ref_norm) < 2e-2, (float(norm), float(ref_norm))
+        assert float(ref_norm) > 0.5                            # the clip was active
+        assert rel(ddp.reduced_grad(ps[big]), rs[big].grad) < 3e-2
+        w0 = ps[big].detach().clone()
+        opt.step()
+        assert rel(ps[big].detach() - w0, -0.1 * rs[big].grad) < 3e-2
+        assert all(getattr(p, "_pda_wire_grad", None) is None for p in ps)     # consumed by the step
+        if fused:
+            ops.cross_entropy(ddp(x), t).backward()
+            assert getattr(ps[big], "_pda_wire_grad", None) is not None
+            ddp.zero_grad()
+            assert all(getattr(p, "_pda_wire_grad", None) is None for p in ps)
