@@ -136,7 +136,10 @@ def _run_ranks(args, argv, comm: str):
 
     def pump():
         for line in p.stdout:
-            lines.append(line.rstrip("\n"))
+            line = line.rstrip("\n")
+            lines.append(line)
+            if not line.startswith("{"):
+                print(line, file=sys.stderr, flush=True)     # live: a run that stops shows where
     t = threading.Thread(target=pump, daemon=True)
     t.start()
     try:
@@ -161,9 +164,6 @@ def _run_ranks(args, argv, comm: str):
                 result = d
             elif "error" in d and err is None:
                 err = d
-    for l in lines:
-        if not l.startswith("{"):
-            print(l, file=sys.stderr)
     return rc, result, err
 
 
@@ -233,6 +233,8 @@ class Deadline:
             def __enter__(self_s):
                 with dl._lock:
                     dl._until, dl._name = time.time() + dl.seconds * factor, name
+                if dl.rank == 0:   # progress on stderr: a run that stops shows where
+                    print(f"[bench] {time.strftime('%H:%M:%S')} stage: {name}", file=sys.stderr, flush=True)
 
             def __exit__(self_s, *exc):
                 with dl._lock:

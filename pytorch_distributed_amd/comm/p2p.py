@@ -337,7 +337,11 @@ class P2PCollectives:
         return _Done() if async_op else None
 
     def barrier(self):
-        self._dist.barrier(group=self.group)
+        # drain the device, then meet on the host side of the group with a CPU tensor: a plain dist.barrier() on a
+        # group that also has a device backend would make torch create an RCCL communicator of its own - which
+        # never completes when the ranks share one GPU, the case this backend exists for
+        torch.cuda.synchronize(self.device)
+        self._dist.all_reduce(torch.zeros(1), group=self.group)
 
     @property
     def device_collectives(self) -> bool:

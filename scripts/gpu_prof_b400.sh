@@ -9,10 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 prof() {  # name, extra bench args...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$name -o r -- python3 $R/bench.py --batch-size 400 --steps 5 --warmup 3 "$@" > $R/gpurun_out/prof_$name.log 2>&1 || { tail -n 20 $R/gpurun_out/prof_$name.log; exit 1; }
-  python3 $R/scripts/trace_last_step.py $R/gpurun_out/prof_$name > $R/gpurun_out/prof_${name}_step.txt 2>&1
+  PDA_TRACE_LAUNCHES=$R/gpurun_out/prof_${name}_launches.txt python3 $R/scripts/trace_last_step.py $R/gpurun_out/prof_$name > $R/gpurun_out/prof_${name}_step.txt 2>&1
   find $R/gpurun_out/prof_$name -name "*kernel_trace.csv" -delete
   echo "$name: $(head -n 1 $R/gpurun_out/prof_${name}_step.txt)"
 }
-prof b400
-PDA_WGRAD_STREAM=0 prof b400_one_stream
+if [ "$1" = "one" ]; then PDA_WGRAD_STREAM=0 prof b400_one_stream --no-compare-stock; exit 0; fi
+prof b400 --no-compare-stock
+PDA_WGRAD_STREAM=0 prof b400_one_stream --no-compare-stock
 prof b400_ddp --force-ddp

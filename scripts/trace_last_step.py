@@ -9,9 +9,13 @@ root = sys.argv[1]
 marker = sys.argv[2] if len(sys.argv) > 2 else "mt_sgd"
 f = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
+extra = {}
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                  r.get("Queue_Id", "?") + "/" + r.get("Stream_Id", "?")))
+    extra[(int(r["Start_Timestamp"]), r["Kernel_Name"])] = (r.get("Grid_Size_X", r.get("Grid_Size", "?")),
+                                                            r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")),
+                                                            r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?"))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
 # one step = from just after the optimizer launch of step n-2 to the optimizer launch of step n-1
@@ -53,3 +57,12 @@ for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
            "bn" if n.startswith("_Z") and "bn_" in n else "other")
     groups[key] += t
 print({k: round(v / 1e6, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1])})
+
+import os
+if os.environ.get("PDA_TRACE_LAUNCHES"):
+    # every launch of the step in issue order: start offset, duration, grid / workgroup size, registers, LDS, name
+    with open(os.environ["PDA_TRACE_LAUNCHES"], "w") as out:
+        t0 = step[0][0]
+        for s_, e_, n, q in step:
+            g, w, v, l = extra.get((s_, n), ("?", "?", "?", "?"))
+            out.write(f"{(s_ - t0) / 1e3:10.1f} us  {(e_ - s_) / 1e3:8.1f} us  q{q:8s} grid {g:>9s} wg {w:>4s} vgpr {v:>4s} lds {l:>7s}  {n[:150]}\n")
