@@ -267,6 +267,8 @@ def worker(args) -> int:
     share_gpu = os.environ.get("PDA_BENCH_SHARE_GPU", "") == "1" and not on_cpu
     if share_gpu:
         local_rank = 0
+        # SyncBatchNorm statistics and the metric vector: through the one-shot peer-memory kernel as well
+        os.environ.setdefault("PDA_P2P_SMALL", "1")
         if world > 1 and args.comm not in ("p2p2",):
             if rank == 0:
                 print(json.dumps({"error": "PDA_BENCH_SHARE_GPU=1 needs --comm p2p2 (RCCL cannot put two ranks "
@@ -396,7 +398,9 @@ def worker(args) -> int:
         if ddp:
             from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP
             kind = comm_kind
-            if kind == "native":
+            if comm_obj is not None:
+                kind = comm_obj             # a later model of this run (bucket sweep): the same communicator
+            elif kind == "native":
                 kind = make_native_comm()
             with deadline.stage("parameter broadcast"):
                 model = DDP(model, device_ids=None if on_cpu else [local_rank], bucket_cap_mb=bucket_mb,

@@ -329,6 +329,15 @@ class P2PCollectives:
             flat.zero_()
             flat[self.rank * t.numel():(self.rank + 1) * t.numel()].copy_(t.reshape(-1))
             self._device_all_reduce(flat, "sum")
+        elif t.is_cuda and out.is_contiguous():
+            # any other dtype (the fp64 dot products of the device Adasum, integer tensors): byte-exact on the
+            # device - every byte travels as one fp32 value next to zeros - so that a caller on another thread (the
+            # hvd engine) never issues a host collective on a group the main thread may be using as well
+            nb = t.numel() * t.element_size()
+            flat = torch.zeros(self.world_size * nb, device=t.device, dtype=torch.float32)
+            flat[self.rank * nb:(self.rank + 1) * nb].copy_(t.contiguous().reshape(-1).view(torch.uint8))
+            self._device_all_reduce(flat, "sum")
+            out.copy_(flat.to(torch.uint8).view(out.dtype).reshape(out.shape))
         else:
             c = t.detach().cpu().contiguous()
             parts = [torch.empty_like(c) for _ in range(self.world_size)]

@@ -56,6 +56,7 @@ from ..ops import multi_tensor as mt, streams as _streams
 from .reducer import BucketPlan
 
 _MiB = 1 << 20
+_P2P_SEQ = 0
 
 
 def _physical_flat(t: torch.Tensor) -> torch.Tensor:
@@ -114,8 +115,13 @@ class DistributedDataParallel(nn.Module):
                 from ..comm.p2p import P2PCollectives
                 from ..comm import native_store, PrefixStore
                 st = native_store()
+                # (a key prefix of its own per wrapper: every rank builds its wrappers in the same order, and a
+                # second set of peer regions must not find the IPC handles the first one published)
+                global _P2P_SEQ
+                _P2P_SEQ += 1
                 comm = P2PCollectives(base.rank, base.world_size, device=dev, overlap=True,
-                                      store=PrefixStore("ddp_p2p", st) if st is not None else None)
+                                      store=PrefixStore(f"ddp_p2p{_P2P_SEQ}", st) if st is not None else None,
+                                      key=f"pda/p2pc{_P2P_SEQ}")
             elif comm == "torch":
                 comm = base
             else:

@@ -11,8 +11,6 @@ run() { local name=$1; shift
 }
 export PDA_BENCH_SHARE_GPU=1 PDA_BENCH_STAGE_TIMEOUT=50
 SMALL="--arch resnet18 --batch-size 64 --image-size 64 --steps 6 --warmup 3"
-run share2_selftest_sweep python -u bench.py --gpus 2 --comm p2p2 --selftest --bucket-mb 8,16,25 $SMALL
-run share2_graph python -u bench.py --gpus 2 --comm p2p2 --graph $SMALL
 run share2_hvd python -u bench.py --gpus 2 --comm p2p2 --engine hvd --sync-bn --eval-steps 3 --selftest $SMALL
 unset PDA_BENCH_SHARE_GPU
 timeout -k 10 170 python -u benchmarks/host_phases.py --precision fp16 > gpurun_out/r3_host_phases_fp16.txt 2>&1 || { tail -n 20 gpurun_out/r3_host_phases_fp16.txt; exit 1; }
