@@ -739,6 +739,15 @@ def worker(args) -> int:
             out.update({"eval_images_per_sec": eval_info["eval_images_per_sec"]})
             out["config"]["eval"] = eval_info
         print(json.dumps(out), flush=True)
+    # The result is out: nothing after this line may turn the run into a failure (a peer that is a little late,
+    # a communicator that takes its time to go away) - a timer ends the process with exit code 0 if the orderly
+    # teardown below does not finish
+    def _bail():
+        time.sleep(45.0)
+        sys.stdout.flush()
+        os._exit(0)
+    threading.Thread(target=_bail, daemon=True).start()
+    deadline.seconds = max(deadline.seconds, 3600.0)
     if watchdog is not None:
         from pytorch_distributed_amd.comm.watchdog import stop_watchdog
         stop_watchdog()

@@ -75,7 +75,13 @@ class Store:
 
     def check(self, keys: Union[str, Iterable[str]]) -> bool:
         keys = [keys] if isinstance(keys, str) else list(keys)
-        return all(self._l.pda_store_check(self._h, k.encode()) == 1 for k in keys)
+        ok = True
+        for k in keys:
+            rc = self._l.pda_store_check(self._h, k.encode())
+            if rc < 0:
+                raise RuntimeError(f"store.check({k!r}) failed: store unreachable")
+            ok = ok and rc == 1
+        return ok
 
     def wait(self, keys: Union[str, Iterable[str]], timeout: Optional[float] = None) -> None:
         keys = [keys] if isinstance(keys, str) else list(keys)
@@ -202,14 +208,13 @@ class Heartbeat:
 
     @staticmethod
     def dead_ranks(store, world_size: int, max_age: float = 10.0):
+        """Ranks without a beacon younger than ``max_age`` seconds.  A store that cannot be reached raises (that is
+        not the same finding as a silent peer)."""
         now, dead = time.time(), []
         for r in range(world_size):
-            try:
-                if not store.check(f"hb/{r}"):
-                    dead.append(r)
-                    continue
-                if now - float(store.get(f"hb/{r}", 1.0)) > max_age:
-                    dead.append(r)
-            except Exception:
+            if not store.check(f"hb/{r}"):
+                dead.append(r)
+                continue
+            if now - float(store.get(f"hb/{r}", 1.0)) > max_age:
                 dead.append(r)
         return dead

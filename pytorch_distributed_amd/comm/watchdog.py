@@ -35,6 +35,7 @@ class CommWatchdog:
         self.interval, self.max_age = float(interval), float(max_age)
         self.on_failure = on_failure or _default_on_failure
         self.failure: Optional[str] = None
+        self._store_down_since: Optional[float] = None
         self._stop = threading.Event()
         self._hb = None
         if store is not None and start_heartbeat:
@@ -61,8 +62,16 @@ class CommWatchdog:
             from .store import Heartbeat
             try:
                 dead = [r for r in Heartbeat.dead_ranks(self.store, self.world_size, self.max_age) if r != self.rank]
+                self._store_down_since = None
             except Exception as e:
-                return f"rendezvous store unreachable: {e}"
+                # the store lives in rank 0's process: at the end of a job it may go away a moment before this
+                # rank stops its own monitor, so only a store that STAYS unreachable counts as a failure
+                now = time.time()
+                if self._store_down_since is None:
+                    self._store_down_since = now
+                if now - self._store_down_since > self.max_age:
+                    return f"rendezvous store unreachable for more than {self.max_age:.0f}s: {e}"
+                return None
             if dead:
                 return f"no heartbeat from rank(s) {dead} for more than {self.max_age:.0f}s"
         return None
@@ -70,7 +79,7 @@ class CommWatchdog:
     def _run(self) -> None:
         while not self._stop.wait(self.interval):
             reason = self._check_once()
-            if reason is not None:
+            if reason is not None and not self._stop.is_set():
                 self.failure = reason
                 try:
                     self.on_failure(reason)
@@ -120,7 +129,7 @@ def start_watchdog(comm=None, interval: float = 1.0, max_age: Optional[float] = 
     if comm is not None and not hasattr(comm, "async_error"):
         comm = None
     if max_age is None:
-        max_age = float(os.environ.get("PDA_WATCHDOG_MAX_AGE", "30"))
+        max_age = float(os.environ.get("PDA_WATCHDOG_MAX_AGE", "60"))
     _ACTIVE["wd"] = CommWatchdog(comm=comm, store=PrefixStore("watchdog", st), rank=info.rank,
                                  world_size=info.world_size, interval=interval, max_age=max_age,
                                  on_failure=on_failure)
