@@ -581,18 +581,35 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """``a [M, K] @ b [N, K]^T (+ bias)`` on this package's any-shape MFMA GEMM (``csrc/kernels/gemm_anyk.hip``):
+    no alignment or divisibility demands on K and N.  fp16 / bf16 / fp32 device matrices with unit inner stride."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    bf = None if bias is None else bias.detach().float().contiguous()
+    _lib.check(_lib.lib().pda_gemm_anyk(_lib.dt(a), a.data_ptr(), b.data_ptr(), _lib.ptr(bf), out.data_ptr(), M, N, K,
+                                        a.stride(0), b.stride(0), N, int(relu), _lib.stream()), "pda_gemm_anyk")
+    return out
+
+
 class _PointwiseGemmFn(torch.autograd.Function):
     """1x1 stride-1 convolution whose channel counts the implicit-GEMM fprop / dgrad kernels do not step
-    through: forward and input gradient are plain ``[pixels, C] x [C, K]`` products on the library GEMM.  The
-    weight gradient is not: its output is a tiny ``[K, C]`` matrix reduced over millions of pixels, a shape the
-    library runs on a handful of workgroups - the split-K wgrad kernel of this package takes it (it only needs
-    channel counts that fill 16-byte vectors)."""
+    through (16, 24, 58, 116, 144, 232 ... in the mobile architectures): forward and input gradient are plain
+    ``[pixels, C] x [C, K]`` products on the any-shape MFMA GEMM of this package (:func:`gemm_nt`), the weight
+    gradient - a tiny ``[K, C]`` matrix reduced over millions of pixels - on the split-K wgrad kernel when the
+    channel counts fill 16-byte vectors, else on the same GEMM over the transposed operands."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         K, Cin = weight.shape[0], weight.shape[1]
         w_lp = weight.detach().reshape(K, Cin).to(x.dtype)
-        y = F.linear(x, w_lp, None if bias is None else bias.detach().to(x.dtype))
+        y = gemm_nt(x.reshape(-1, Cin), w_lp, None if bias is None else bias.detach()).view(*x.shape[:-1], K)
         ctx.save_for_backward(x, w_lp)
         ctx.meta = (weight.dtype, bias is not None)
         return y
@@ -605,12 +622,14 @@ class _PointwiseGemmFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(dy.reshape(-1, K), w_lp).view(x.shape)
+            dx = gemm_nt(dy.reshape(-1, K), w_lp.t().contiguous()).view(x.shape)
         if ctx.needs_input_grad[1]:
             vec = 16 // x.element_size()
             d = wgrad_gpu(dy, x.contiguous(), 1, 1, (1, 1), (0, 0)) if (K % vec == 0 and Cin % vec == 0) else None
             if d is None:
-                d = torch.matmul(dy.reshape(-1, K).t(), x.reshape(-1, Cin)).float()
+                # dW [K, Cin] = dY^T [K, pixels] x X [pixels, Cin]: both operands transposed so that the reduction
+                # runs along rows (tiny outputs: the transposes are the cost of an odd channel count)
+                d = gemm_nt(dy.reshape(-1, K).t().contiguous(), x.reshape(-1, Cin).t().contiguous()).float()
             dw = d.reshape(K, Cin, 1, 1).to(wdtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
@@ -644,7 +663,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias=None, stride=(1, 1), pad=
     tiled_in, tiled_out = igemm_tiles(Cin, x.dtype), igemm_tiles(K, x.dtype)
     if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and not (tiled_in and tiled_out):
         # a pointwise conv is a plain [pixels, Cin] x [Cin, K] GEMM: channel counts the implicit-GEMM kernels
-        # do not tile (16, 24, 144, ... in MobileNet) go to the library GEMM instead of the scalar fallback
+        # do not tile (16, 24, 144, ... in MobileNet) go to the any-shape MFMA GEMM instead of the scalar fallback
         y = _PointwiseGemmFn.apply(x, weight, bias)
         if relu:
             from .elementwise import relu as _relu

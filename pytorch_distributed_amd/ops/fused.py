@@ -264,8 +264,9 @@ class _ConvBnActFn(torch.autograd.Function):
             if r is None:
                 if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
                     # pointwise conv with a filter count the dgrad kernel does not step through (16, 24 in
-                    # MobileNet): dX = dY [pixels, K] x W [K, Cin] on the library GEMM
-                    dx = torch.matmul(dy.reshape(-1, K), cache.low_precision(weight, dy.dtype).reshape(K, Cin))
+                    # MobileNet): dX = dY [pixels, K] x W [K, Cin] on the any-shape MFMA GEMM
+                    dx = C.gemm_nt(dy.reshape(-1, K),
+                                   cache.low_precision(weight, dy.dtype).reshape(K, Cin).t().contiguous())
                     dx = dx.view(x.shape)
                 else:
                     dx = torch.empty_like(x)

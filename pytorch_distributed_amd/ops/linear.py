@@ -9,9 +9,9 @@ classifier layers of AlexNet / VGG: 128 x 25088 x 4096) has only a few dozen out
 the forward splits K over workgroups (``conv.gemm_splitk``) and the input gradient runs as a split-K
 "weight gradient" whose pixels are the N outputs, which also reads the weight as it is stored.  What the reference reaches through
 ``nn.Linear`` inside torchvision's ResNets (/root/reference/2.distributed.py:213) and in the MNIST net
-(/root/reference/5.2.horovod_pytorch_mnist.py:42-43).  Shapes the MFMA kernels do not take (a reduction
-dimension that is not a multiple of 32 half / 16 float elements, e.g. the 50 -> 10 layer) and CPU tensors use
-the library GEMM.
+(/root/reference/5.2.horovod_pytorch_mnist.py:42-43).  Shapes the tiled kernels do not take (a reduction
+dimension that is not a multiple of 32 half / 16 float elements, e.g. the 50 -> 10 layer) run on the any-shape
+MFMA GEMM (``csrc/kernels/gemm_anyk.hip``); CPU tensors use stock PyTorch.
 """
 from __future__ import annotations
 
@@ -169,6 +169,35 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _AnyShapeLinearFn(torch.autograd.Function):
+    """Linear layer whose shape the tiled kernels do not take (an in-feature count that is not a whole number of
+    K steps - the MNIST net's 320 -> 50 -> 10 head in fp32 has such - or an odd out-feature count): all three
+    products on the any-shape MFMA GEMM (``csrc/kernels/gemm_anyk.hip``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .conv import gemm_nt
+        w = weight.detach() if weight.dtype == x.dtype else weight.detach().to(x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        return gemm_nt(x, w, None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .conv import gemm_nt
+        x, w = ctx.saved_tensors
+        wdtype, bdtype = ctx.meta
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nt(dy, w.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            dw = gemm_nt(dy.t().contiguous(), x.t().contiguous()).to(wdtype)
+        if bdtype is not None and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0).to(bdtype)
+        return dx, dw, db
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
            cache: Optional[LinearCache] = None) -> torch.Tensor:
     """``x [.., K] @ weight[N, K]^T + bias`` in ``x``'s dtype (fp32 accumulation on the matrix cores)."""
@@ -177,6 +206,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if supported(x2, weight):
         y = _LinearFn.apply(x2, weight, bias, cache if cache is not None else LinearCache())
         return y.view(*lead, weight.shape[0])
+    if x2.is_cuda and x2.dtype in (torch.float32, torch.float16, torch.bfloat16) and x2.shape[0] > 0:
+        return _AnyShapeLinearFn.apply(x2, weight, bias).view(*lead, weight.shape[0])
     w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
     b = bias if bias is None or bias.dtype == x.dtype else bias.to(x.dtype)
-    return F.linear(x, w, b)
+    return F.linear(x, w, b)   # CPU tensors

@@ -345,3 +345,54 @@ def test_filter_count_padding_with_bias_and_relu(dtype, relu):
         yr.backward(g.to(dtype).float())
         assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
         assert rel(w.grad, wr.grad) < tol and rel(b.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 58, 58), (1000, 116, 24), (257, 10, 50), (64, 232, 116), (129, 130, 33),
+                                   (5, 7, 3), (4096, 256, 320)])
+def test_any_shape_gemm_matches_fp32(dtype, M, N, K):
+    """csrc/kernels/gemm_anyk.hip against an fp32 product: channel counts that are no multiple of anything (the K
+    tail and the rows / columns past the last tile multiply exact zeros), vector and element fetch paths, bias
+    and ReLU in the write-out, a strided A operand."""
+    from pytorch_distributed_amd.ops.conv import gemm_nt
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K + 3, device=DEV).to(dtype)[:, :K]          # row pitch K + 3: never 16-byte aligned rows
+    b = torch.randn(N, K, device=DEV).to(dtype)
+    bias = torch.randn(N, device=DEV)
+    ref = a.float() @ b.float().t()
+    tol = 1e-5 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 1.5e-2)
+
+    def rel(x, r):
+        return float((x.float() - r).norm() / (r.norm() + 1e-30))
+    assert rel(gemm_nt(a, b), ref) < tol
+    assert rel(gemm_nt(a.contiguous(), b, bias, relu=True), torch.relu(ref + bias)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(58, 58), (24, 144), (116, 232), (16, 50)])
+def test_odd_channel_pointwise_conv_runs_on_the_own_gemm(dtype, cin, cout, monkeypatch):
+    """ShuffleNetV2 / MobileNetV2 pointwise layers (58, 116, 232, 24, 144 channels) forward and backward against
+    F.conv2d in fp32 - with the library GEMM entry points made to fail, so a silent fallback cannot pass."""
+    def boom(*a, **k):
+        raise AssertionError("library GEMM reached from a pointwise conv")
+    monkeypatch.setattr(F, "linear", boom)
+    monkeypatch.setattr(torch, "matmul", boom)
+    torch.manual_seed(3)
+    x = torch.randn(3, 9, 11, cin, device=DEV, dtype=dtype, requires_grad=True)
+    w = (torch.randn(cout, cin, 1, 1, device=DEV) * 0.1).requires_grad_(True)
+    bias = torch.randn(cout, device=DEV, requires_grad=True)
+    y = ops.conv2d(x, w, bias, (1, 1), (0, 0))
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.detach().to(dtype).float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+
+    def rel(a, r):
+        return float((a.detach().float() - r.detach()).norm() / (r.detach().norm() + 1e-30))
+    assert rel(y, yr.permute(0, 2, 3, 1)) < tol
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+    yr.backward(g.to(dtype).float())
+    assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+    assert rel(w.grad, wr.grad) < tol and rel(bias.grad, br.grad) < tol
