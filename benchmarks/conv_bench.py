@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--cfgs", default="0", help="comma separated igemm tile cfgs (0 auto, 1 128x128, 2 128x64, 3 64x64)")
-    ap.add_argument("--wcfgs", default="0", help="wgrad cfgs (0 auto, 1 128x128, 2 64x64, 3 64x128, +8 = 32-pixel steps; 12 256x128, 13 128x256)")
+    ap.add_argument("--wcfgs", default="0", help="wgrad cfgs (0 auto, 1 128x128, 2 64x64, 3 64x128, +8 = 32-pixel steps; 12 256x128, 13 128x256; LDS-DMA ring: 65 128x128, 68 256x128, 69 128x256, 70 128x128 64-pixel steps)")
     ap.add_argument("--nsplits", default="0")
     ap.add_argument("--wblocks", default="", help="wgrad: target workgroup counts (overrides --nsplits)")
     ap.add_argument("--only", default="fdw", help="which of f(prop) d(grad) w(grad) to time")
@@ -89,7 +89,7 @@ def main():
             tile = wc & 7
             if tile == 0:
                 tile = 1 if (co % 128 == 0 and ktot % 128 == 0) else 2
-            tlm, tln = {1: (128, 128), 2: (64, 64), 3: (64, 128), 4: (256, 128), 5: (128, 256)}[tile]
+            tlm, tln = {1: (128, 128), 2: (64, 64), 3: (64, 128), 4: (256, 128), 5: (128, 256), 6: (128, 128)}[tile]
             tiles = -(-co // tlm) * -(-ktot // tln)
             splits = [int(c) for c in a.nsplits.split(",")]
             if a.wblocks:

@@ -61,6 +61,9 @@ _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
+# + 64: the LDS-DMA ring kernel (csrc/kernels/wgrad_ring.hip), 16-bit operands without the normalise-on-load input:
+# 65 = 128x128 (4 x 32 pixels), 68 / 69 = 256x128 / 128x256 (3 x 32), 70 = 128x128 (3 x 64)
+_WGRAD_RING_CFGS = (65, 68, 69, 70)
 
 
 def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
@@ -308,7 +311,9 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
     if cfg == 0 and nsplit == 0 and backends.benchmark and geom is None:
         cfg = _tuned_cfg("wgrad", (dy.dtype, N, Hi, Wi, Ci, Ho, Wo, K, R, S, tuple(stride), tuple(pad), workspace,
-                                   backends.deterministic, in_affine is not None), _WGRAD_CFGS,
+                                   backends.deterministic, in_affine is not None),
+                         _WGRAD_CFGS + (_WGRAD_RING_CFGS if dy.element_size() == 2 and (
+                             in_affine is None or (tuple(pad) == (0, 0) and R == 1 and S == 1)) else ()),
                          lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, None, None, workspace,
                                              in_affine))
     cfg &= (1 << 30) - 1
@@ -319,10 +324,16 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
     if in_affine is not None:
         if x.element_size() != 2:
             return None
-        rc = l.pda_conv_wgrad_xf(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), in_affine[0].data_ptr(),
-                                 in_affine[1].data_ptr(), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S, stride[0],
-                                 stride[1], pad[0], pad[1], cfg, nsplit, _lib.ptr(ws),
-                                 0 if ws is None else ws.numel() * 4, _lib.stream())
+        fn = l.pda_conv_wgrad_ring_xf if cfg & 64 else l.pda_conv_wgrad_xf
+        if cfg & 64:
+            cfg &= 39
+        rc = fn(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), in_affine[0].data_ptr(),
+                in_affine[1].data_ptr(), N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, R, S, stride[0], stride[1], pad[0],
+                pad[1], cfg, nsplit, _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
+    elif cfg & 64:
+        rc = l.pda_conv_wgrad_ring(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
+                                   Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg & 39, nsplit,
+                                   _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
     else:
         rc = l.pda_conv_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, Hi, Wi, Ci, sn, sh, sw,
                               Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, nsplit,
