@@ -47,12 +47,20 @@ template <> struct Mfma32r<bf16> {
   }
 };
 
+// One ds_read_b64_tr_b16 as a bare instruction.  The builtin form of this read counts as a possible LDS *write* in
+// the compiler's wait-count pass, which then drains every LDS-DMA in flight (s_waitcnt vmcnt(0)) in front of the
+// first fragment read of a step - the ring would never hold more than the tile being read.  Behind an asm statement
+// the compiler sees no LDS access at all, so the kernel orders these reads itself: counted lgkmcnt waits (LDS
+// operations return in order) followed by a scheduling barrier, before anything consumes the registers.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read_raw(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
 template <typename T>
-__device__ __forceinline__ typename Mfma32r<T>::frag tr_read(const unsigned char* p0, const unsigned char* p1) {
-  typedef s16x4 __attribute__((address_space(3))) * lp;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p1));
-  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+__device__ __forceinline__ typename Mfma32r<T>::frag join_halves(s16x4 lo, s16x4 hi) {
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(typename Mfma32r<T>::frag, v);
 }
 
@@ -236,37 +244,55 @@ wgrad_ring_kernel(WRArgs a) {
       for (int e = 0; e < 8; ++e) { xsc[j][e] = sc; xsf[j][e] = sf; }
     }
   }
-  frag fa[2][MI], fb[2][NI];
-  auto fetch = [&](auto buf_, const unsigned char* sb, auto kk_) {
+  // fragment halves (pixel rows +0..3 and +4..7 of a group) as they come out of the reads; joined at the MFMAs
+  s16x4 alo[2][MI], ahi[2][MI], blo[2][NI], bhi[2][NI];
+  constexpr int READS = 2 * (MI + NI);   // LDS instructions of one 16-pixel group
+  static_assert(READS <= 15, "a group's reads must fit the lgkmcnt field");
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr)lds;
+  auto fetch = [&](auto buf_, unsigned sb, auto kk_) {
     constexpr int B = decltype(buf_)::value, kk = decltype(kk_)::value;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-      fa[B][i] = tr_read<T>(sb + offA[i] + kk * 16 * PY, sb + offA[i] + kk * 16 * PY + 4 * PY);
+    for (int i = 0; i < MI; ++i) {
+      alo[B][i] = tr_read_raw<kk * 16 * PY>(sb + offA[i]);
+      ahi[B][i] = tr_read_raw<kk * 16 * PY + 4 * PY>(sb + offA[i]);
+    }
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      fb[B][j] = tr_read<T>(sb + offB[j] + kk * 16 * PX, sb + offB[j] + kk * 16 * PX + 4 * PX);
+    for (int j = 0; j < NI; ++j) {
+      blo[B][j] = tr_read_raw<kk * 16 * PX>(sb + offB[j]);
+      bhi[B][j] = tr_read_raw<kk * 16 * PX + 4 * PX>(sb + offB[j]);
+    }
   };
-  auto mfmas = [&](auto buf_) {
-    constexpr int B = decltype(buf_)::value;
-    if constexpr (XF) {
+  // MFMAs of the group in register set B once all but `pending` of the LDS reads issued so far have returned
+  auto mfmas = [&](auto buf_, auto pending_) {
+    constexpr int B = decltype(buf_)::value, pending = decltype(pending_)::value;
+    __builtin_amdgcn_s_waitcnt(wr_waitcnt(63, pending));
+    __builtin_amdgcn_sched_barrier(0);   // nothing that reads the fragment registers may move above the wait
+    frag fa[MI], fb[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[B][j] = affine_relu(fb[B][j], xsc[j], xsf[j]);
+    for (int i = 0; i < MI; ++i) fa[i] = join_halves<T>(alo[B][i], ahi[B][i]);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      fb[j] = join_halves<T>(blo[B][j], bhi[B][j]);
+      if constexpr (XF) fb[j] = affine_relu(fb[j], xsc[j], xsf[j]);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32r<T>::run(fa[B][i], fb[B][j], acc[i][j]);
+      for (int j = 0; j < NI; ++j) acc[i][j] = Mfma32r<T>::run(fa[i], fb[j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);   // and the next group's reads stay behind these MFMAs' operand fetch
   };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using IR = std::integral_constant<int, READS>;
   auto compute = [&](int ST) {
-    const unsigned char* sb = lds + ST * STAGE_BYTES;
-    fetch(std::integral_constant<int, 0>{}, sb, std::integral_constant<int, 0>{});
-    if constexpr (KG >= 2) fetch(std::integral_constant<int, 1>{}, sb, std::integral_constant<int, 1>{});
-    mfmas(std::integral_constant<int, 0>{});
-    if constexpr (KG >= 3) fetch(std::integral_constant<int, 0>{}, sb, std::integral_constant<int, 2>{});
-    if constexpr (KG >= 2) mfmas(std::integral_constant<int, 1>{});
-    if constexpr (KG >= 4) fetch(std::integral_constant<int, 1>{}, sb, std::integral_constant<int, 3>{});
-    if constexpr (KG >= 3) mfmas(std::integral_constant<int, 0>{});
-    if constexpr (KG >= 4) mfmas(std::integral_constant<int, 1>{});
+    const unsigned sb = lds_base + ST * STAGE_BYTES;
+    // reads run one group ahead of the MFMAs in a second register set
+    fetch(I0{}, sb, I0{});
+    if constexpr (KG >= 2) { fetch(I1{}, sb, I1{}); mfmas(I0{}, IR{}); } else { mfmas(I0{}, I0{}); }
+    if constexpr (KG >= 3) { fetch(I0{}, sb, std::integral_constant<int, 2>{}); mfmas(I1{}, IR{}); }
+    else if constexpr (KG == 2) { mfmas(I1{}, I0{}); }
+    if constexpr (KG >= 4) { fetch(I1{}, sb, std::integral_constant<int, 3>{}); mfmas(I0{}, IR{}); mfmas(I1{}, I0{}); }
+    else if constexpr (KG == 3) { mfmas(I0{}, I0{}); }
     static_assert(KG <= 4, "at most 64 pixels per step");
   };
 
