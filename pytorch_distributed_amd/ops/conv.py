@@ -58,6 +58,9 @@ _TUNED: dict = {}
 # slower than the tiles below on every ResNet-50 3x3 layer - the step time is set by the per-step wait / barrier /
 # fragment-read latency, not by L2 bandwidth (profiles/igemm_stamps_r2.txt) - so the tuner does not try it.)
 _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
+# 33: the A-stationary pointwise kernel (csrc/kernels/pointwise_astat.hip): unpadded 1x1, 64 / 128 / 256 / 512 input
+# channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
+_FPROP_PW_CFG = 33
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
@@ -147,8 +150,14 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
         if not (xs.dtype == xf.dtype == x.dtype and xs.numel() == xf.numel() == Ci and xs.is_contiguous()
                 and xf.is_contiguous()):
             raise ValueError("fprop_gpu: in_affine must be two contiguous [Ci] tensors of the input's dtype")
+    pw_ok = (geom is None and R == 1 and S == 1 and tuple(pad) == (0, 0) and res is None and not relu and bias is None
+             and x.element_size() == 2 and Ci in (64, 128, 256, 512) and K % 8 == 0)
+    if cfg == _FPROP_PW_CFG and not pw_ok:
+        return None
     if cfg == 0 and backends.benchmark and geom is None:
         cands = _FPROP_XF_CFGS if in_affine is not None else (_FPROP_CFGS if res is None else _DGRAD_EX_CFGS)
+        if pw_ok:
+            cands = cands + (_FPROP_PW_CFG,)
         cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats,
                                    in_affine is not None), cands,
                          lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias,
@@ -158,7 +167,8 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     psum = psq = None
     slots = 0
     if stats:
-        bm = l.pda_conv_igemm_bm(M, K, cfg, _lib.dt(x), int(res is not None))
+        bm = (l.pda_conv_pw_bm(Ci) if cfg == _FPROP_PW_CFG else
+              l.pda_conv_igemm_bm(M, K, cfg, _lib.dt(x), int(res is not None)))
         tiles_m = (M + bm - 1) // bm
         if stats_buf is not None and tiles_m > stats_buf.shape[1]:
             slots = stats_buf.shape[1]
@@ -168,7 +178,12 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
             psum, psq = part[0], part[1]
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K or not bias.is_contiguous()):
         raise ValueError("fprop_gpu: bias must be a contiguous fp32 [K] tensor")
-    if in_affine is not None:
+    if cfg == _FPROP_PW_CFG:
+        rc = l.pda_conv_pw_fprop(_lib.dt(x), x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(),
+                                 None if in_affine is None else in_affine[0].data_ptr(),
+                                 None if in_affine is None else in_affine[1].data_ptr(), _lib.ptr(psum), _lib.ptr(psq),
+                                 N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, K, stride[0], stride[1], slots, _lib.stream())
+    elif in_affine is not None:
         rc = l.pda_conv_igemm_xf(_lib.dt(x), x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(), in_affine[0].data_ptr(),
                                  in_affine[1].data_ptr(), _lib.ptr(psum), _lib.ptr(psq), N, Hi, Wi, Ci, sn, sh, sw,
                                  Ho, Wo, K, R, S, stride[0], stride[1], pad[0], pad[1], cfg, slots, _lib.stream())

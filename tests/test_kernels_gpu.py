@@ -213,6 +213,42 @@ def test_wgrad_lds_dma_ring(case, cfg, dtype):
     assert rel_err(a.permute(0, 3, 1, 2), wr.grad) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, K, stride: every supported depth; channel ranges of one / several tiles and chunks, ragged in
+    # tiles (96, 200) and chunks (320); row counts that end inside a wave's block, a wave and a workgroup
+    (4, 14, 14, 64, 256, 1), (3, 9, 7, 128, 512, 1), (2, 12, 12, 256, 1024, 1), (5, 7, 7, 512, 2048, 1),
+    (2, 10, 10, 64, 96, 1), (1, 5, 5, 128, 200, 1), (6, 8, 8, 256, 320, 1), (2, 16, 16, 256, 512, 2),
+    (3, 15, 13, 128, 64, 2), (40, 4, 4, 512, 1032, 1), (1, 1, 1, 64, 8, 1)])
+def test_pointwise_a_stationary_fprop(case, dtype):
+    """cfg 33: A operand resident in registers, weights through an LDS-DMA ring, pipelined write-out with
+    statistics - plain and with the input normalised on load, against fp32 references."""
+    N, H, W, Cin, K, s = case
+    torch.manual_seed(9)
+    x = torch.randn(N, H, W, Cin, device=DEV).to(dtype)
+    w = (torch.randn(K, 1, 1, Cin, device=DEV) / Cin ** 0.5).to(dtype).permute(0, 3, 1, 2)
+    scale = (torch.rand(Cin, device=DEV) + 0.5).to(dtype)
+    shift = (torch.rand(Cin, device=DEV) - 0.5).to(dtype)
+    act = torch.relu(x.float() * scale.float() + shift.float()).to(dtype)
+    for aff, xin in ((None, x), ((scale, shift), act)):
+        yr = _ref_conv(xin, w, s, 0)
+        y = C.fprop_gpu(x, C.krsc(w), (s, s), (0, 0), cfg=33, in_affine=aff)
+        assert y is not None
+        assert rel_err(y, yr) < TOL[dtype], ("fprop", aff is not None)
+        y2, psum, psq = C.fprop_gpu(x, C.krsc(w), (s, s), (0, 0), stats=True, cfg=33, in_affine=aff)
+        assert torch.equal(y2, y)
+        yf = y.float().view(-1, K)
+        assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
+        assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
+        buf = torch.zeros(2, 2, K, device=DEV)
+        y3, ps, pq = C.fprop_gpu(x, C.krsc(w), (s, s), (0, 0), stats=True, cfg=33, in_affine=aff, stats_buf=buf)
+        assert torch.equal(y3, y)
+        assert rel_err(ps.sum(0), yf.sum(0)) < 2e-3 and rel_err(pq.sum(0), (yf * yf).sum(0)) < 2e-3
+    # not covered: filters with taps or padding, other depths, epilogue extras
+    assert C.fprop_gpu(x, C.krsc(w), (s, s), (1, 1), cfg=33) is None
+    assert C.fprop_gpu(x, C.krsc(w), (s, s), (0, 0), relu=True, cfg=33) is None
+
+
 def test_batched_weight_transpose_refresh():
     """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
     torch.manual_seed(41)
