@@ -1592,7 +1592,7 @@ static const long long kBigTiles = [] {
 // cfg: low 3 bits 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (each of the 2x2 waves owns
 // 128x64 outputs); bit 3 forces 64-byte K rows.  16-bit types only, LDS-DMA operand ring: 5 = 256x128 with
 // 4x2 waves and three 64-deep stages, 6 = 128x128 with 2x2 waves and four 32-deep stages, 7 = 256x256 with
-// 4x2 waves (64x128 outputs each) and four 32-deep stages.
+// 4x2 waves (64x128 outputs each) and four 32-deep stages, 13 (5 + 8) = 256x128 with 2x2 waves and three 32-deep stages.
 // big_ok: 16-bit plain kernel.  With the 128x128 tile every wave re-reads a 64-row A and a 64-row B slice
 // per 16 MFMAs and waits on those reads; a 128x64 wave tile moves 25 % fewer LDS bytes per MFMA and measured
 // 5-10 % faster in isolation on the deep layers at 28x28 and 14x14 - as long as there are enough tiles to fill the chip
@@ -1632,7 +1632,8 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   const bool shallow = ES == 2 && (cfg & 7) == 0 && !extras && (long long)a.R * a.S * a.Ci <= kShallowK;
   const int tile = pick_tile(a.M, a.Co, cfg, ES == 2 && !extras);
   const bool use128 = k128 && (cfg & 8) == 0 && !shallow && !((cfg & 7) == 0 && tile == 4);
-  if ((tile == 4 || tile == 7) && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
+  const bool ring4 = tile == 5 && (cfg & 8) != 0;  // 256x128 ring with 2x2 waves
+  if ((tile == 4 || tile == 7 || ring4) && extras) return -9;  // the epilogue extras are not built for 16 vectors per thread
   if (tile == 8) {
     // cfg bit 6: 256x128 slab tile (8 waves): odd square-ish filters with "same" padding at stride 1, 32-channel
     // slices; the slots a tile of 256 consecutive output pixels can reach (its rows and images in zero-padded
@@ -1651,6 +1652,9 @@ static int dispatch_igemm(const ConvArgs& a, int dgrad, int cfg, hipStream_t st)
   if (tile >= 5) {
     if (a.in_scale != nullptr) return -11;  // the LDS-DMA tiles move operands past the registers
     if constexpr (ES == 2) {
+      // 5 + 8: the same 256x128 outputs on 2x2 waves of 128x64 (three fragment reads per four MFMAs instead of
+      // four) with 32-deep steps in three buffers - the geometry of the ring weight-gradient kernel
+      if (ring4) return launch_igemm<T, 256, 128, 64, 2, 3>(a, dgrad, st);
       if (tile == 5 && k128) return launch_igemm<T, 256, 128, 128, 4, 3>(a, dgrad, st);
       if (tile == 6) return launch_igemm<T, 128, 128, 64, 2, 4>(a, dgrad, st);
       if (tile == 7) return launch_igemm<T, 256, 256, 64, 4, 4>(a, dgrad, st);

@@ -57,7 +57,7 @@ _TUNED: dict = {}
 # read one LDS-resident slab of input pixels.  It cuts the L2 traffic of the A operand ~9x but measured 5-40 %
 # slower than the tiles below on every ResNet-50 3x3 layer - the step time is set by the per-step wait / barrier /
 # fragment-read latency, not by L2 bandwidth (profiles/igemm_stamps_r2.txt) - so the tuner does not try it.)
-_FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7)
+_FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7, 13)   # 13: 256x128 ring on 2x2 waves (128x64 each), 3 x 32-deep
 # 33: the A-stationary pointwise kernel (csrc/kernels/pointwise_astat.hip): unpadded 1x1, 64 / 128 / 256 / 512 input
 # channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
 _FPROP_PW_CFG = 33

@@ -86,7 +86,7 @@ def test_conv_tile_configs(cfg):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [5, 6, 7])
+@pytest.mark.parametrize("cfg", [5, 6, 7, 13])
 @pytest.mark.parametrize("case", [
     # N, H, W, Cin, K, R, stride, pad: ring shorter than / equal to / longer than its depth, ragged M and Co
     (3, 10, 10, 128, 192, 3, 1, 1), (2, 14, 14, 128, 256, 1, 1, 0), (5, 9, 7, 64, 96, 1, 1, 0),
@@ -102,7 +102,7 @@ def test_conv_lds_dma_ring_tiles(case, cfg, dtype):
     yr = _ref_conv(xr, w.float(), s, p)
     r = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), stats=True, cfg=cfg)
     if r is None:
-        assert cfg & 7 == 5 and Cin % 64 != 0   # the 64-deep ring needs 128-byte K rows
+        assert cfg == 5 and Cin % 64 != 0   # the 64-deep ring needs 128-byte K rows
         return
     y, psum, psq = r
     assert rel_err(y, yr) < TOL[dtype], "fprop"
@@ -110,7 +110,8 @@ def test_conv_lds_dma_ring_tiles(case, cfg, dtype):
     assert rel_err(psum.sum(0), yf.sum(0)) < 2e-3
     assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 2e-3
     res = torch.randn_like(y)
-    if cfg & 7 != 7:   # the 256x256 tile has no fused-epilogue build
+    noex = cfg in (7, 13)   # the 256x256 tile and the 2x2-wave 256x128 tile have no fused-epilogue build
+    if not noex:
         y2 = C.fprop_gpu(x, C.krsc(w), (s, s), (p, p), res=res, relu=True, cfg=cfg)
         assert rel_err(y2, torch.relu(yr + res.float())) < TOL[dtype], "fprop+res+relu"
     dy = torch.randn_like(yr).to(dtype)
@@ -120,10 +121,10 @@ def test_conv_lds_dma_ring_tiles(case, cfg, dtype):
     for extra in ((0, 16) if s == 2 else (0,)):
         dx = C.dgrad_gpu(dy, wt, (H, W), (s, s), (p, p), cfg=cfg | extra)
         if dx is None:
-            assert cfg & 7 == 5 and K % 64 != 0
+            assert cfg == 5 and K % 64 != 0
             continue
         assert rel_err(dx, xr.grad) < TOL[dtype], ("dgrad", extra)
-        if cfg & 7 != 7:
+        if not noex:
             dx = C.dgrad_gpu(dy, wt, (H, W), (s, s), (p, p), res=rx, cfg=cfg | extra)
             assert rel_err(dx, xr.grad + rx.float()) < TOL[dtype], ("dgrad+res", extra)
 
