@@ -89,7 +89,7 @@ def main():
             tile = wc & 7
             if tile == 0:
                 tile = 1 if (co % 128 == 0 and ktot % 128 == 0) else 2
-            tlm, tln = {1: (128, 128), 2: (64, 64), 3: (64, 128), 4: (256, 128), 5: (128, 256), 6: (128, 128)}[tile]
+            tlm, tln = {1: (128, 128), 2: (64, 64) if wc < 64 else (64, 256), 3: (64, 128), 4: (256, 128), 5: (128, 256), 6: (128, 128)}[tile]
             tiles = -(-co // tlm) * -(-ktot // tln)
             splits = [int(c) for c in a.nsplits.split(",")]
             if a.wblocks:

@@ -85,17 +85,28 @@ constexpr int wr_waitcnt(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14
 // ONE channel (its output column), so scale and shift are two per-lane constants per fragment and the transform is
 // eight packed VALU operations next to sixteen-pass MFMAs.  Rows past the end of the pixel range arrive as zeros
 // and become relu(shift), but their dY rows are zeros too; padding taps would not be (the host refuses those).
-template <typename T, int TM, int TN, int BKP, int STAGES, bool LIN, bool XF>
+// WM: waves along the Co dimension of the tile (2 x 2, or 1 x 4 for the 64-row tile: every wave then keeps a 64 x 64
+// sub-tile, two fragment reads per MFMA pair, instead of a 32-row sliver).
+// Chunk swizzle of an LDS image by pixel row: 256 / 512-byte rows XOR their 64-byte segment index with px & 3, 128-byte
+// rows (two per 256-byte bank row) with (px / 2) & 1 - either way the four pixel rows a 16-lane group of a transposing
+// read touches land in four different bank quarters.
+template <int PITCH> __device__ __forceinline__ int px_swizzle(int px) {
+  return PITCH % 256 == 0 ? (px & 3) : ((px >> 1) & 1);
+}
+template <typename T, int TM, int TN, int BKP, int STAGES, bool LIN, bool XF, int WM = 2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 wgrad_ring_kernel(WRArgs a) {
-  static_assert(sizeof(T) == 2 && (TM == 128 || TM == 256) && (TN == 128 || TN == 256), "16-bit, 256/512-byte pixel rows");
+  static_assert(sizeof(T) == 2 && (TM == 64 || TM == 128 || TM == 256) && (TN == 128 || TN == 256), "16-bit, 128/256/512-byte pixel rows");
+  static_assert(WM == 1 || WM == 2, "four waves");
   static_assert(BKP % 16 == 0 && STAGES >= 2 && STAGES <= 4, "ring geometry");
   constexpr int PY = TM * 2, PX = TN * 2;                     // bytes per pixel row of the two LDS images
   constexpr int STAGE_BYTES = BKP * (PY + PX);
   constexpr int NPY = BKP * PY / 4096, NPX = BKP * PX / 4096;  // DMA instructions per wave and step, per operand
   static_assert(NPY >= 1 && NPX >= 1, "every wave moves at least one piece per operand");
   constexpr int PIECES = NPY + NPX;
-  constexpr int WTM = TM / 2, WTN = TN / 2, MI = WTM / 32, NI = WTN / 32;
+  constexpr int WN = 4 / WM;
+  constexpr int WTM = TM / WM, WTN = TN / WN, MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1, "every wave owns at least one 32 x 32 block");
   constexpr int KG = BKP / 16;                                 // 16-pixel MFMA groups per step
   constexpr unsigned OOB = 0x80000000u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -104,7 +115,7 @@ wgrad_ring_kernel(WRArgs a) {
   typedef typename Mfma32r<T>::frag frag;
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int tiles_k = (a.Co + TM - 1) / TM;
@@ -132,7 +143,7 @@ wgrad_ring_kernel(WRArgs a) {
   constexpr int RPPY = 1024 / PY, CPRY = PY / 16, RPPX = 1024 / PX, CPRX = PX / 16;
   const int lrY = lane / CPRY, slY = lane % CPRY, lrX = lane / CPRX, slX = lane % CPRX;
   const int pxY0 = wid * RPPY + lrY, pxX0 = wid * RPPX + lrX;   // pixel row of the lane's first piece (+ 4 * RPP per piece)
-  const int cY = slY ^ ((pxY0 & 3) << 2), cX = slX ^ ((pxX0 & 3) << 2);
+  const int cY = slY ^ (px_swizzle<PY>(pxY0) << 2), cX = slX ^ (px_swizzle<PX>(pxX0) << 2);
   const long long rangeY = (long long)(mend - mbeg) * a.Co * 2;
   const auto rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(DY) + (long long)mbeg * a.Co, 0,
                                                         (int)(rangeY > 0 ? rangeY : 0), 0x00020000);
@@ -217,13 +228,13 @@ wgrad_ring_kernel(WRArgs a) {
   // channels 4p .. 4p + 3
   const int li = lane & 15, lg = lane >> 4;
   const int prow0 = 8 * (lg >> 1) + (li >> 2);
-  const int sw6 = (prow0 & 3) << 6;
+  const int swA = px_swizzle<PY>(prow0) << 6, swB = px_swizzle<PX>(prow0) << 6;
   unsigned offA[MI], offB[NI];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) offA[i] = prow0 * PY + (((wm * WTM + i * 32 + 16 * (lg & 1) + 4 * (li & 3)) * 2) ^ sw6);
+  for (int i = 0; i < MI; ++i) offA[i] = prow0 * PY + (((wm * WTM + i * 32 + 16 * (lg & 1) + 4 * (li & 3)) * 2) ^ swA);
 #pragma unroll
   for (int j = 0; j < NI; ++j)
-    offB[j] = BKP * PY + prow0 * PX + (((wn * WTN + j * 32 + 16 * (lg & 1) + 4 * (li & 3)) * 2) ^ sw6);
+    offB[j] = BKP * PY + prow0 * PX + (((wn * WTN + j * 32 + 16 * (lg & 1) + 4 * (li & 3)) * 2) ^ swB);
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -374,7 +385,7 @@ wr_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long lo
   }
 }
 
-template <typename T, int TM, int TN, int BKP, int STAGES, bool XF>
+template <typename T, int TM, int TN, int BKP, int STAGES, bool XF, int WM = 2>
 int launch_ring(WRArgs a, bool lin, int nsplit, bool det, long long slab_bytes, hipStream_t st) {
   const int tiles = ((a.Co + TM - 1) / TM) * ((a.Ktot + TN - 1) / TN);
   if (nsplit <= 0) {
@@ -402,9 +413,9 @@ int launch_ring(WRArgs a, bool lin, int nsplit, bool det, long long slab_bytes, 
   if ((long long)a.pix_per_split * a.Co * 2 >= 0x7fffffffLL) return -10;
   if (lin) {
     if ((long long)a.pix_per_split * a.Ci * 2 >= 0x7fffffffLL) return -10;
-    hipLaunchKernelGGL((wgrad_ring_kernel<T, TM, TN, BKP, STAGES, true, XF>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_ring_kernel<T, TM, TN, BKP, STAGES, true, XF, WM>), dim3(tiles, nsplit), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((wgrad_ring_kernel<T, TM, TN, BKP, STAGES, false, XF>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_ring_kernel<T, TM, TN, BKP, STAGES, false, XF, WM>), dim3(tiles, nsplit), dim3(256), 0, st, a);
   }
   if (slabs) {
     const long long n4 = n / 4;
@@ -445,7 +456,11 @@ int wgrad_ring_impl(int dtype, const void* dy, const void* x, float* dw, const v
     if ((long long)(Ho - 1) * stride_h + R > Hi || (long long)(Wo - 1) * stride_w + S > Wi) return -11;
   }
   // the gathered operand is addressed with 32-bit byte offsets from the tensor base
-  if (((long long)N * sn + (long long)Hi * sh + (long long)Wi * sw + Ci) * 2 >= 0x7fffffffLL) return -10;
+  {
+    const long long hmax = std::min<long long>(Hi - 1, (long long)(Ho - 1) * stride_h - pad_h + R - 1);
+    const long long wmax = std::min<long long>(Wi - 1, (long long)(Wo - 1) * stride_w - pad_w + S - 1);
+    if (((long long)(N - 1) * sn + hmax * sh + wmax * sw + Ci) * 2 >= 0x7fffffffLL) return -10;
+  }
   const bool lin = R == 1 && S == 1 && stride_h == 1 && stride_w == 1 && pad_h == 0 && pad_w == 0 && sw == Ci &&
                    sh == (long long)Wi * Ci && sn == (long long)Hi * Wi * Ci && Ho == Hi && Wo == Wi;
   const bool det = (cfg & 32) != 0;
@@ -453,6 +468,7 @@ int wgrad_ring_impl(int dtype, const void* dy, const void* x, float* dw, const v
 #define PDA_WR(T, XF)                                                                                         \
   switch (tile) {                                                                                             \
     case 1: return launch_ring<T, 128, 128, 32, 4, XF>(a, lin, nsplit, det, workspace_bytes, stream);         \
+    case 2: return launch_ring<T, 64, 256, 32, 3, XF, 1>(a, lin, nsplit, det, workspace_bytes, stream);       \
     case 4: return launch_ring<T, 256, 128, 32, 3, XF>(a, lin, nsplit, det, workspace_bytes, stream);         \
     case 5: return launch_ring<T, 128, 256, 32, 3, XF>(a, lin, nsplit, det, workspace_bytes, stream);         \
     case 6: return launch_ring<T, 128, 128, 64, 3, XF>(a, lin, nsplit, det, workspace_bytes, stream);         \
@@ -471,6 +487,7 @@ int wgrad_ring_impl(int dtype, const void* dy, const void* x, float* dw, const v
 
 // Same contract as pda_conv_wgrad (dw zero-initialised or holding the gradient to accumulate into; workspace:
 // optional scratch for split-K slabs).  cfg low 3 bits: 1 = 128(Co) x 128 tile, 32-pixel steps, four ring buffers;
+// 2 = 64 x 256 on 1 x 4 waves, three buffers (layers with 64 output channels);
 // 4 = 256 x 128 and 5 = 128 x 256, three buffers; 6 = 128 x 128 with 64-pixel steps, three buffers; bit 5 = run-to-run
 // reproducible reduction.  <0: shape not covered (fp32, channel counts that do not fill 16-byte vectors, operands
 // beyond the 32-bit offset range) - the caller uses pda_conv_wgrad.

@@ -65,8 +65,8 @@ _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the re
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
 # + 64: the LDS-DMA ring kernel (csrc/kernels/wgrad_ring.hip), 16-bit operands without the normalise-on-load input:
-# 65 = 128x128 (4 x 32 pixels), 68 / 69 = 256x128 / 128x256 (3 x 32), 70 = 128x128 (3 x 64)
-_WGRAD_RING_CFGS = (65, 68, 69, 70)
+# 65 = 128x128 (4 x 32 pixels), 66 = 64x256 on 1 x 4 waves, 68 / 69 = 256x128 / 128x256 (3 x 32), 70 = 128x128 (3 x 64)
+_WGRAD_RING_CFGS = (65, 66, 68, 69, 70)
 
 
 def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
@@ -324,12 +324,12 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
         sn, sh, sw = Hi * Wi * Ci, Wi * Ci, Ci
     else:
         N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
-    if cfg == 0 and nsplit == 0 and backends.benchmark and geom is None:
+    if cfg == 0 and nsplit == 0 and backends.benchmark:
         cfg = _tuned_cfg("wgrad", (dy.dtype, N, Hi, Wi, Ci, Ho, Wo, K, R, S, tuple(stride), tuple(pad), workspace,
-                                   backends.deterministic, in_affine is not None),
+                                   backends.deterministic, in_affine is not None, None if geom is None else tuple(geom)),
                          _WGRAD_CFGS + (_WGRAD_RING_CFGS if dy.element_size() == 2 and (
                              in_affine is None or (tuple(pad) == (0, 0) and R == 1 and S == 1)) else ()),
-                         lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, None, None, workspace,
+                         lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, geom, None, workspace,
                                              in_affine))
     cfg &= (1 << 30) - 1
     if backends.deterministic:

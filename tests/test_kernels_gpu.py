@@ -182,7 +182,7 @@ def test_wgrad_tiles_and_splits():
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [65, 68, 69, 70])
+@pytest.mark.parametrize("cfg", [65, 66, 68, 69, 70])
 @pytest.mark.parametrize("case", [
     # N, H, W, Cin, K, R, stride, pad: plain-matrix X (1x1 s1), gathered X with padding / stride, ragged channel
     # counts and pixel ranges, feature maps smaller than the filter
@@ -248,6 +248,24 @@ def test_pointwise_a_stationary_fprop(case, dtype):
     # not covered: filters with taps or padding, other depths, epilogue extras
     assert C.fprop_gpu(x, C.krsc(w), (s, s), (1, 1), cfg=33) is None
     assert C.fprop_gpu(x, C.krsc(w), (s, s), (0, 0), relu=True, cfg=33) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_wgrad_ring_on_the_stem_geometry(dtype):
+    """The 7x7 stem runs as a 7x1 filter over rows of 8 pixels x 4 channels of the zero-bordered image (a gather
+    geometry with overlapping 'pixels'): the ring kernels against the register-staged one."""
+    N, H, W = 6, 64, 48
+    Hp, Wp, Ho, Wo, geom = fused._stem_geometry(N, H, W, 7, 7, (2, 2), (3, 3))
+    torch.manual_seed(12)
+    xp = fused.input_to_nhwc(torch.randn(N, 3, H, W, device=DEV), dtype, 4, (3, 3), Wp)
+    dy = torch.randn(N, Ho, Wo, 64, device=DEV).to(dtype)
+    ref = C.wgrad_gpu(dy, xp, 7, 1, (2, 1), (0, 0), geom=geom, cfg=1)
+    assert ref is not None
+    for cfg in (65, 66, 69):
+        for nsplit in (0, 3):
+            dw = C.wgrad_gpu(dy, xp, 7, 1, (2, 1), (0, 0), geom=geom, cfg=cfg, nsplit=nsplit)
+            assert dw is not None
+            assert rel_err(dw, ref) < 2e-3, (cfg, nsplit)
 
 
 def test_batched_weight_transpose_refresh():
@@ -1274,7 +1292,7 @@ def test_conv_input_normalised_on_load(case, cfg, dtype):
         # that never touch padding (negative shifts here: rows past the pixel range must still add nothing)
         shift2 = (torch.rand(Cin, device=DEV) - 0.5).to(dtype)
         act2 = torch.relu(x.float() * scale.float() + shift2.float()).to(dtype)
-        for wcfg in (65, 68, 69, 70):
+        for wcfg in (65, 66, 68, 69, 70):
             for nsplit in (0, 1, 3):
                 dw = C.wgrad_gpu(dy, x, R, R, (s, s), (p, p), cfg=wcfg, nsplit=nsplit, in_affine=(scale, shift2))
                 if p != 0:
