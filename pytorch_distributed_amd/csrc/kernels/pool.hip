@@ -5,55 +5,104 @@
 // /root/reference/2.distributed.py:213 and F.max_pool2d in
 // /root/reference/5.2.horovod_pytorch_mnist.py:46-47).
 #include "common.h"
-#include "pool_gather.h"
 
-template <typename T, int EPC>
-__global__ void __launch_bounds__(256)
+// Both max-pool kernels give one image row to a workgroup: the (image, row) split and the window rows are scalar
+// work done once, a thread's only division is its element index by the vectors per pixel (a shift when that is a
+// power of two).  With one flat index per thread the seven integer divisions of the index arithmetic cost more
+// VALU time than the kernel's memory traffic takes (ResNet-50 stem at batch 400: 377 us backward for a 180 us floor).
+__device__ __forceinline__ int div_pow2_or(int v, int d, int shift) { return shift >= 0 ? v >> shift : v / d; }
+
+// KW: compile-time window size (0 = any, from `k`): all taps of a window are then requested before the first
+// comparison instead of one load latency after the other.
+template <typename T, int EPC, int KW>
+__global__ void __launch_bounds__(512)
 maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* __restrict__ idx, int N, int H,
                    int W, int C, int Ho, int Wo, int k, int s, int p, const float* __restrict__ scale,
-                   const float* __restrict__ shift) {
+                   const float* __restrict__ shift, int vshift) {
   // scale/shift given: x is a pre-normalisation tensor and the pooled value is relu(x*scale+shift), rounded
   // to T exactly as a separate BatchNorm pass would have stored it (the ResNet stem: the 112x112 activation
   // is never written)
   const int vpr = C / EPC;
-  const long long total = (long long)N * Ho * Wo * vpr;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % vpr);
-    long long r = i / vpr;
-    const int wo = (int)(r % Wo); r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    float best[EPC], sc[EPC], sf[EPC];
+  const long long row = blockIdx.x;            // n * Ho + ho
+  const int ho = (int)(row % Ho);
+  const long long n = row / Ho;
+  const int h0 = ho * s - p;
+  const int a_lo = h0 < 0 ? -h0 : 0, a_hi = (h0 + k > H ? H - h0 : k);   // window rows inside the image
+  const T* __restrict__ xn = x + n * (long long)H * W * C;
+  // the workgroup size is a multiple of the vectors per pixel whenever it can be (host): a thread then keeps its
+  // channels from one element to the next and loads their coefficients once
+  const bool fixed_cv = blockDim.x % vpr == 0;
+  float sc[EPC], sf[EPC];
+  if (scale && fixed_cv) {
+    const int cv = threadIdx.x % vpr;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[cv * EPC + e]; sf[e] = shift[cv * EPC + e]; }
+  }
+  for (int j = threadIdx.x; j < Wo * vpr; j += blockDim.x) {
+    const int wo = div_pow2_or(j, vpr, vshift);
+    const int cv = j - wo * vpr;
+    float best[EPC];
     unsigned char bi[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
-    if (scale) {
+    if (scale && !fixed_cv) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { sc[e] = scale[cv * EPC + e]; sf[e] = shift[cv * EPC + e]; }
     }
-    for (int a = 0; a < k; ++a) {
-      const int h = ho * s - p + a;
-      if ((unsigned)h >= (unsigned)H) continue;
-      for (int b = 0; b < k; ++b) {
-        const int w = wo * s - p + b;
-        if ((unsigned)w >= (unsigned)W) continue;
-        VecN<T, EPC> v = loadN<T, EPC>(x + (((long long)n * H + h) * W + w) * C + cv * EPC);
+    const int w0 = wo * s - p;
+    const int b_lo = w0 < 0 ? -w0 : 0, b_hi = (w0 + k > W ? W - w0 : k);
+    auto take = [&](const VecN<T, EPC>& v, int a, int b) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          float f = ElemTraits<T>::to_f32(v.v[e]);
-          if (scale) f = ElemTraits<T>::to_f32(ElemTraits<T>::from_f32(fmaxf(f * sc[e] + sf[e], 0.f)));
-          if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(a * k + b); }
-        }
+      for (int e = 0; e < EPC; ++e) {
+        float f = ElemTraits<T>::to_f32(v.v[e]);
+        if (scale) f = ElemTraits<T>::to_f32(ElemTraits<T>::from_f32(fmaxf(f * sc[e] + sf[e], 0.f)));
+        if (f > best[e] || f != f) { best[e] = f; bi[e] = (unsigned char)(a * k + b); }
       }
+    };
+    if constexpr (KW > 0) {
+      VecN<T, EPC> v[KW * KW];
+      bool ok[KW * KW];
+#pragma unroll
+      for (int a = 0; a < KW; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b) {
+          ok[a * KW + b] = a >= a_lo && a < a_hi && b >= b_lo && b < b_hi;
+          const long long o = ok[a * KW + b] ? ((long long)(h0 + a) * W + (w0 + b)) * C + cv * EPC : (long long)cv * EPC;
+          v[a * KW + b] = loadN<T, EPC>(xn + o);
+        }
+#pragma unroll
+      for (int a = 0; a < KW; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+          if (ok[a * KW + b]) take(v[a * KW + b], a, b);
+    } else {
+      for (int a = a_lo; a < a_hi; ++a)
+        for (int b = b_lo; b < b_hi; ++b)
+          take(loadN<T, EPC>(xn + ((long long)(h0 + a) * W + (w0 + b)) * C + cv * EPC), a, b);
     }
+    const long long i = row * Wo * vpr + j;
     VecN<T, EPC> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(best[e]);
     storeN<T, EPC>(out + i * EPC, o);
     if (idx) {
+      if constexpr (EPC == 8) {   // one 8-byte store instead of eight byte stores
+        u32x2 pk = {0u, 0u};
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) idx[i * EPC + e] = bi[e];
+        for (int e = 0; e < 4; ++e) {
+          pk[0] |= (unsigned)bi[e] << (8 * e);
+          pk[1] |= (unsigned)bi[4 + e] << (8 * e);
+        }
+        *reinterpret_cast<u32x2*>(idx + i * EPC) = pk;
+      } else if constexpr (EPC == 4) {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk |= (unsigned)bi[e] << (8 * e);
+        *reinterpret_cast<unsigned*>(idx + i * EPC) = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) idx[i * EPC + e] = bi[e];
+      }
     }
   }
 }
@@ -61,21 +110,58 @@ maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, unsigned char* 
 // One thread per input pixel-vector: sum the output gradients of every window
 // whose arg-max byte points back at this pixel (no atomics, deterministic).
 template <typename T, int EPC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx, T* __restrict__ dx, int N,
-                   int H, int W, int C, int Ho, int Wo, int k, int s, int p) {
+                   int H, int W, int C, int Ho, int Wo, int k, int s, int p, int vshift, int sshift) {
   const int vpr = C / EPC;
-  const long long total = (long long)N * H * W * vpr;
-  const PoolGeom g = {H, W, Ho, Wo, k, s, p};
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % vpr);
+  const long long row = blockIdx.x;            // n * H + h
+  const int h = (int)(row % H);
+  const long long n = row / H;
+  // windows ho with ho*s - p <= h <= ho*s - p + k - 1
+  int ho_lo = h + p - k + 1 + s - 1;
+  ho_lo = ho_lo < 0 ? 0 : ho_lo / s;
+  int ho_hi = (h + p) / s;
+  if (ho_hi > Ho - 1) ho_hi = Ho - 1;
+  for (int j = threadIdx.x; j < W * vpr; j += blockDim.x) {
+    const int w = div_pow2_or(j, vpr, vshift);
+    const int cv = j - w * vpr;
+    int wo_lo = w + p - k + 1 + s - 1;
+    wo_lo = wo_lo < 0 ? 0 : div_pow2_or(wo_lo, s, sshift);
+    int wo_hi = div_pow2_or(w + p, s, sshift);
+    if (wo_hi > Wo - 1) wo_hi = Wo - 1;
     float acc[EPC];
-    pool_grad_gather<T, EPC>(dout, idx, g, i / vpr, cv, vpr, acc);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    struct Cand { VecN<T, EPC> gv; unsigned char ib[EPC]; };
+    auto fetch = [&](int ho, int wo) {
+      Cand c;
+      const long long o = (((n * Ho + ho) * Wo + wo) * vpr + cv) * EPC;
+      c.gv = loadN<T, EPC>(dout + o);
+      if constexpr (EPC == 8) {
+        *reinterpret_cast<u32x2*>(c.ib) = *reinterpret_cast<const u32x2*>(idx + o);
+      } else if constexpr (EPC == 4) {
+        *reinterpret_cast<unsigned int*>(c.ib) = *reinterpret_cast<const unsigned int*>(idx + o);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) c.ib[e] = idx[o + e];
+      }
+      return c;
+    };
+    auto take = [&](const Cand& c, int ho, int wo) {
+      const int a = h - (ho * s - p), b = w - (wo * s - p);
+      const unsigned char me = (unsigned char)(a * k + b);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        if (c.ib[e] == me) acc[e] += ElemTraits<T>::to_f32(c.gv.v[e]);
+    };
+    // (requesting all four candidate windows of a k <= 2 s pool up front measured slower, 306 vs 249 us on the
+    // ResNet stem: a pixel lies in 2.25 windows on average and the extra requests cost more than the latency)
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) take(fetch(ho, wo), ho, wo);
     VecN<T, EPC> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.v[e] = ElemTraits<T>::from_f32(acc[e]);
-    storeN<T, EPC>(dx + i * EPC, o);
+    storeN<T, EPC>(dx + (row * W * vpr + j) * EPC, o);
   }
 }
 
@@ -215,6 +301,17 @@ static inline int ew_blocks(long long n) {
     default: return -6;                                                          \
   }
 
+static int log2_or_minus1(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (v > 0 && (1 << l) == v) ? l : -1;
+}
+// threads of a one-row workgroup: whole waves; the whole row at once up to 512 threads, else 256 per pass
+static int pool_row_threads(long long elems) {
+  const long long t = ((elems + 63) / 64) * 64;
+  return (int)(t < 64 ? 64 : (t > 512 ? 256 : t));
+}
+
 PDA_EXPORT int pda_maxpool_fwd(int dtype, const void* x, void* out, unsigned char* idx, int N, int H, int W, int C,
                                int Ho, int Wo, int k, int s, int p, const float* scale, const float* shift,
                                hipStream_t st) {
@@ -224,8 +321,17 @@ PDA_EXPORT int pda_maxpool_fwd(int dtype, const void* x, void* out, unsigned cha
   if (k * k > 255) return -1;
   const long long total = (long long)N * Ho * Wo * (C / epc);
   if (total == 0) return 0;
-  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_fwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
-                                           (const T*)x, (T*)out, idx, N, H, W, C, Ho, Wo, k, s, p, scale, shift));
+  const long long rows = (long long)N * Ho;
+  if (rows > 0x7fffffffLL) return -4;
+  const int vpr = C / epc, nt = pool_row_threads((long long)Wo * vpr);
+#define PDA_MAXPOOL_FWD(KW_)                                                                                         \
+  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_fwd_kernel<T, EPC, KW_>), dim3((unsigned)rows), dim3(nt), 0, st, \
+                                           (const T*)x, (T*)out, idx, N, H, W, C, Ho, Wo, k, s, p, scale, shift,      \
+                                           log2_or_minus1(vpr)))
+  if (k == 3) { PDA_MAXPOOL_FWD(3); }
+  else if (k == 2) { PDA_MAXPOOL_FWD(2); }
+  else { PDA_MAXPOOL_FWD(0); }
+#undef PDA_MAXPOOL_FWD
   return pda_check_launch();
 }
 
@@ -236,8 +342,12 @@ PDA_EXPORT int pda_maxpool_bwd(int dtype, const void* dout, const unsigned char*
   if (!vec) epc = 1;
   const long long total = (long long)N * H * W * (C / epc);
   if (total == 0) return 0;
-  PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_bwd_kernel<T, EPC>), dim3(ew_blocks(total)), dim3(256), 0, st,
-                                           (const T*)dout, idx, (T*)dx, N, H, W, C, Ho, Wo, k, s, p));
+  const long long rows = (long long)N * H;
+  if (rows > 0x7fffffffLL) return -4;
+  const int vpr = C / epc, nt = pool_row_threads((long long)W * vpr);
+PDA_DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((maxpool_bwd_kernel<T, EPC>), dim3((unsigned)rows), dim3(nt), 0, st,
+                                           (const T*)dout, idx, (T*)dx, N, H, W, C, Ho, Wo, k, s, p,
+                                           log2_or_minus1(vpr), log2_or_minus1(s)));
   return pda_check_launch();
 }
 
