@@ -9,6 +9,9 @@ Two shared libraries are produced under ``pytorch_distributed_amd/lib``:
   rendezvous stores, shared-memory collective backend, reducer core, Horovod-style
   background engine), compiled with g++.
 
+* ``_pda_pyext.<abi>.so`` - a small CPython extension (``csrc/pyext/*.cc``): the per-parameter gradient-ready
+  hook of ``DistributedDataParallel`` as a C callable (optional: the Python hooks are the fallback).
+
 ``python -m pytorch_distributed_amd._build`` rebuilds whatever is out of date.
 """
 from __future__ import annotations
@@ -32,6 +35,8 @@ CXX = os.environ.get("PDA_CXX") or shutil.which("g++") or "g++"
 
 KERNEL_LIB = LIB / "libpda_kernels.so"
 RUNTIME_LIB = LIB / "libpda_runtime.so"
+import sysconfig  # noqa: E402
+PYEXT_LIB = LIB / ("_pda_pyext" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
 def _stamp(paths) -> str:
@@ -127,8 +132,27 @@ def build_runtime(force: bool = False, verbose: bool = False) -> Path | None:
     return RUNTIME_LIB
 
 
+def build_pyext(force: bool = False, verbose: bool = False) -> Path | None:
+    """The CPython extension; skipped (None) where the interpreter's headers are not installed."""
+    srcs = sorted((CSRC / "pyext").glob("*.cc"))
+    inc = sysconfig.get_paths().get("include")
+    if not srcs or not inc or not (Path(inc) / "Python.h").exists():
+        return None
+    stamp = _stamp(srcs)
+    if not force and not _needs(PYEXT_LIB, stamp):
+        return PYEXT_LIB
+    LIB.mkdir(exist_ok=True)
+    if verbose:
+        print("[pda build] g++ pyext", flush=True)
+    _run([CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", inc, "-o", str(PYEXT_LIB)]
+         + [str(s) for s in srcs])
+    _mark(PYEXT_LIB, stamp)
+    return PYEXT_LIB
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_runtime(force=force, verbose=verbose)
+    build_pyext(force=force, verbose=verbose)
     build_kernels(force=force, verbose=verbose)
 
 

@@ -53,6 +53,7 @@ import torch.nn as nn
 from torch.autograd import Variable
 
 from ..ops import multi_tensor as mt, streams as _streams
+from . import _pyext
 from .reducer import BucketPlan
 
 _MiB = 1 << 20
@@ -61,6 +62,39 @@ _P2P_SEQ = 0
 
 def _physical_flat(t: torch.Tensor) -> torch.Tensor:
     return torch.as_strided(t, (t.numel(),), (1,))
+
+
+_HOST_T: Dict[str, List[float]] = {}
+
+
+def _install_host_timers(ddp) -> None:
+    """Diagnostics (``PDA_DDP_HOST_TIMERS=1``): host seconds and call counts of the wrapper's own work per phase,
+    printed at exit - the hooks run on autograd's thread, where cProfile does not see them."""
+    import atexit
+    import time
+
+    def timed(name, fn):
+        rec = _HOST_T.setdefault(name, [0.0, 0])
+
+        def run(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                rec[0] += time.perf_counter() - t0
+                rec[1] += 1
+        return run
+
+    for name in ("_launch", "_pack_and_reduce", "_finalize_backward", "_first_ready", "_broadcast_buffers_cached"):
+        setattr(ddp, name, timed(name, getattr(ddp, name)))
+    coll = ddp._coll
+    for name in ("all_reduce", "broadcast"):
+        try:
+            setattr(coll, name, timed("coll." + name, getattr(coll, name)))
+        except Exception:
+            pass
+    atexit.register(lambda: print("DDP host timers: " + ", ".join(
+        f"{k} {1e3 * v[0]:.1f} ms / {v[1]} calls" for k, v in _HOST_T.items()), flush=True))
 
 
 class _Bucket:
@@ -143,7 +177,8 @@ class DistributedDataParallel(nn.Module):
         self.gradient_average = gradient_average
         self.predivide = float(gradient_predivide_factor)
         self.delay_allreduce = delay_allreduce
-        self.require_backward_grad_sync = True
+        self._hook_state = None     # shared flags of the C ready hooks (set below when the extension is built)
+        self._require_sync = True
         self._rebuild_pending = rebuild_buckets and not delay_allreduce and self._active
         self._params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self._index: Dict[int, int] = {id(p): i for i, p in enumerate(self._params)}
@@ -198,12 +233,27 @@ class DistributedDataParallel(nn.Module):
         self._plan = BucketPlan(sizes, int(cap), int(first))
         self._buckets: List[_Bucket] = []
         self._build_buckets()
+        if os.environ.get("PDA_DDP_HOST_TIMERS") == "1":
+            _install_host_timers(self)
         self._hooks = []
+        # The per-parameter ready hook as a C callable (csrc/pyext/ready_hook.cc) when the extension is built:
+        # the .grad identity check and the plan's mark_ready() without a Python frame or a ctypes transition.
+        ext = _pyext.module() if os.environ.get("PDA_DDP_NATIVE_HOOKS", "1") != "0" else None
+        self._native_hooks = []
+        if ext is not None:
+            self._hook_state = ext.HookState()
+            self._hook_state.enabled = int(self._require_sync and self._active)
+            mark = self._plan.mark_ready_address()
+            n = len(self._params)
+            self._native_hooks = [ext.ReadyHook(self._hook_state, self._plan.handle(), mark, i, n, self._view_of[i],
+                                                self._first_ready, self._launch_index, self._fold_grad)
+                                  for i in range(n)]
         for i, p in enumerate(self._params):
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            hook = self._native_hooks[i] if self._native_hooks else None
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook if hook is not None else self._make_hook(i)))
             # convolution ops of this package may write straight into .grad and call this instead
             p._pda_direct_grad = True
-            p._pda_grad_ready = self._make_direct_ready(i)
+            p._pda_grad_ready = hook if hook is not None else self._make_direct_ready(i)
             p._pda_ddp = weakref.ref(self)
             if getattr(p, "_pda_fused_opt", False):
                 self.enable_fused_wire()
@@ -305,8 +355,38 @@ class DistributedDataParallel(nn.Module):
                 bk.views.append(view)
                 self._view_of[i] = view
             self._buckets.append(bk)
+        for i, h in enumerate(getattr(self, "_native_hooks", ())):
+            h.view = self._view_of[i]
 
     # ------------------------------------------------------------------ hooks
+    @property
+    def require_backward_grad_sync(self) -> bool:
+        return self._require_sync
+
+    @require_backward_grad_sync.setter
+    def require_backward_grad_sync(self, on: bool) -> None:
+        self._require_sync = bool(on)
+        if self._hook_state is not None:
+            self._hook_state.enabled = int(self._require_sync and self._active)
+
+    # callbacks of the C hooks: first ready gradient of a backward, a completed bucket, a replaced .grad
+    def _first_ready(self) -> None:
+        self._callback_queued = True
+        self._in_backward = True
+        Variable._execution_engine.queue_callback(self._finalize_backward)
+
+    def _launch_index(self, b: int) -> None:
+        self._launch(self._buckets[b])
+
+    def _fold_grad(self, i: int, param) -> None:
+        view = self._view_of[i]
+        g = param.grad
+        if g is not None and g is not view and g.data_ptr() != view.data_ptr():
+            view.copy_(g)
+            param.grad = view
+        elif g is not None and g is not view:
+            param.grad = view   # another Python object over the same memory: restore the identity the hook checks
+
     def _make_hook(self, i: int):
         def hook(param):
             self._on_grad_ready(i, param)
@@ -380,6 +460,8 @@ class DistributedDataParallel(nn.Module):
     def _finalize_backward(self) -> None:
         self._callback_queued = False
         self._in_backward = False
+        if self._hook_state is not None:
+            self._hook_state.queued = 0
         _streams.join()
         if not self.require_backward_grad_sync or not self._active:
             return

@@ -26,6 +26,14 @@ class BucketPlan:
         except Exception:
             pass
 
+    def handle(self) -> int:
+        """Address of the native plan (for the C ready hooks)."""
+        return int(self._h)
+
+    def mark_ready_address(self) -> int:
+        """Address of ``pda_reducer_mark_ready`` (called by the C ready hooks without going through ctypes)."""
+        return ctypes.cast(self._l.pda_reducer_mark_ready, ctypes.c_void_p).value
+
     @property
     def num_buckets(self) -> int:
         return self._l.pda_reducer_num_buckets(self._h)

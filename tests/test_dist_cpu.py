@@ -130,6 +130,10 @@ def test_ddp_param_grad_is_the_reduced_gradient_by_default():
     spawn(W.ddp_grad_semantics, args=(2, free_port()), nprocs=2)
 
 
+def test_ddp_native_ready_hooks_match_python_hooks():
+    spawn(W.ddp_native_hooks, args=(2, free_port()), nprocs=2)
+
+
 def test_apex_flavoured_ddp():
     spawn(W.apex_flavour, args=(2, free_port()), nprocs=2)
 

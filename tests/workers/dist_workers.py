@@ -201,3 +201,48 @@ def ddp_grad_semantics(rank, world, port):
             assert getattr(ps[big], "_pda_wire_grad", None) is not None
             ddp.zero_grad()
             assert all(getattr(p, "_pda_wire_grad", None) is None for p in ps)
+
+
+def ddp_native_hooks(rank, world, port):
+    """The C ready hooks (csrc/pyext/ready_hook.cc) against the Python closures: same reduced gradients after a
+    plain backward, after zero_grad(set_to_none=True) replaced every .grad, and across a no_sync() accumulation."""
+    _init(rank, world, port)
+    import os
+    from pytorch_distributed_amd.parallel import DistributedDataParallel as DDP, _pyext
+    assert _pyext.module() is not None, "the extension is built in-tree by python -m pytorch_distributed_amd._build"
+    torch.manual_seed(3)
+    X, T = torch.randn(6 * world, 20), torch.randn(6 * world, 4)
+    x, t = X[rank * 6:(rank + 1) * 6], T[rank * 6:(rank + 1) * 6]
+
+    def run(native):
+        os.environ["PDA_DDP_NATIVE_HOOKS"] = "1" if native else "0"
+        torch.manual_seed(11)
+        net = torch.nn.Sequential(torch.nn.Linear(20, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                                  torch.nn.Linear(64, 4))
+        ddp = DDP(net, bucket_cap_mb=0.01, first_bucket_mb=0.005)   # several buckets
+        assert bool(ddp._native_hooks) == native
+        out = []
+        ((ddp(x) - t) ** 2).mean().backward()
+        out.append([p.grad.clone() for p in net.parameters()])
+        net.zero_grad(set_to_none=True)                     # every .grad is replaced by a fresh tensor next time
+        ((ddp(x) - t) ** 2).mean().backward()
+        out.append([p.grad.clone() for p in net.parameters()])
+        assert all(p.grad.data_ptr() == ddp._view_of[i].data_ptr() for i, p in enumerate(net.parameters()))
+        ddp.zero_grad()
+        with ddp.no_sync():
+            ((ddp(x) - t) ** 2).mean().backward()
+            local = [p.grad.clone() for p in net.parameters()]
+        ((ddp(x) - t) ** 2).mean().backward()               # reduces the sum of both passes
+        out.append([p.grad.clone() for p in net.parameters()])
+        out.append(local)
+        return out
+
+    a, b = run(True), run(False)
+    for ga, gb in zip(a, b):
+        for u, v in zip(ga, gb):
+            assert torch.allclose(u, v, rtol=1e-6, atol=1e-7)
+    # the local pass of no_sync differs between the ranks, the reduced ones do not
+    import torch.distributed as dist
+    gathered = [torch.zeros_like(a[2][0]) for _ in range(world)]
+    dist.all_gather(gathered, a[2][0])
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
