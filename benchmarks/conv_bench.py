@@ -77,10 +77,11 @@ def main():
         io_f = (x.numel() + M * co) * es
         best = {}
         for cfg in [int(c) for c in a.cfgs.split(",")]:
-            if "f" in a.only:
+            # (a configuration that does not cover the shape returns None at once: not a measurement)
+            if "f" in a.only and C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=cfg) is not None:
                 t = timeit(lambda: C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=cfg), a.iters)
                 best.setdefault("fprop", []).append((t, cfg))
-            if "d" in a.only:
+            if "d" in a.only and cfg != 33 and C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg) is not None:
                 t = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg), a.iters)
                 best.setdefault("dgrad", []).append((t, cfg))
         dw = torch.zeros(co, k, k, ci, device=dev)
@@ -95,6 +96,8 @@ def main():
             if a.wblocks:
                 splits = sorted({max(1, round(int(b) / tiles)) for b in a.wblocks.split(",")})
             for ns in splits:
+                if C.wgrad_gpu(dy, x, k, k, (s, s), (pad, pad), cfg=wc, nsplit=ns, out=dw) is None:
+                    continue
                 t = timeit(lambda: C.wgrad_gpu(dy, x, k, k, (s, s), (pad, pad), cfg=wc, nsplit=ns, out=dw), a.iters)
                 best.setdefault("wgrad", []).append((t, (wc, ns * tiles if a.wblocks else ns)))
         line = {"H": h, "Cin": ci, "Cout": co, "k": k, "s": s, "count": count, "GFLOP": round(flops / 1e9, 2),
