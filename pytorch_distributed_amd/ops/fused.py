@@ -21,6 +21,7 @@ from typing import Optional
 import torch
 
 from . import _lib, conv as C, norm as Nm, pool as P, streams
+from .. import backends
 
 
 # Smallest GEMM depth (Cout*R*S of the consuming conv's dgrad) for which the dgrad epilogue also takes the
@@ -68,6 +69,11 @@ _MASK_BITS = os.environ.get("PDA_RELU_MASK_BITS", "1") == "1"
 # the pass it saves (ResNet-50, batch 400: 34.1 vs 33.5 ms per step); PDA_DEFER_BN_APPLY=all forces it for both.
 _DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") in ("1", "all")
 _DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
+
+
+# Backward of a bottleneck's last 1x1 conv on the 64 -> 256 geometry: BatchNorm backward apply + dgrad + wgrad in one
+# pass over the 256-channel tensors (csrc/kernels/bottleneck_tail_bwd.hip) instead of three kernels and five passes.
+_FUSE_TAIL_BWD = os.environ.get("PDA_FUSE_TAIL_BWD", "1") == "1"
 
 
 class BNBackwardLink:
@@ -205,6 +211,28 @@ class _ConvBnActFn(torch.autograd.Function):
             presums, ctx.out_link.sums = ctx.out_link.sums, None
             presums_clear = presums is not None and presums is ctx.out_link.sums_buf
             ctx.out_link.y = None
+        link = ctx.in_link
+        if (_FUSE_TAIL_BWD and train_stats and ctx.premasked and presums is not None and ctx.in_aff is not None
+                and (K, Cin, R, S) == (256, 64, 1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0)
+                and dout.element_size() == 2 and dout.dtype == x.dtype and y is not None and dalias is None
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not backends.deterministic
+                and link is not None and link.y is not None and link.y.data_ptr() == x.data_ptr() and link.relu
+                and link.remask and C.grad_sink(weight) is not None):
+            # BatchNorm backward apply, dgrad (with the producer's ReLU mask and BatchNorm sums) and wgrad in one pass:
+            # dy is formed per tile on chip and never stored
+            coef, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False, False, group,
+                                          ctx.beta, cache.stats_buffer(K, dout.device), presums=presums,
+                                          presums_clear=presums_clear, coef_only=True)
+            r = C.bottleneck_tail_bwd(dout.view(-1, K), y.view(-1, K), coef, x.view(-1, Cin), ctx.in_aff,
+                                      cache.transposed(weight, dout.dtype), C.grad_sink(weight))
+            if r is None:
+                raise RuntimeError("conv_bn_act: the fused bottleneck-tail backward refused a shape its caller checked")
+            dx, link.sums = r[0].view(x.shape), r[1]
+            C.notify_grad_ready(weight)
+            if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
+                dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
+            return (dx, None, dg, db, dout if has_res else None, None, None, None, None, None, None, None, None, None,
+                    None)
         if train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)

@@ -223,8 +223,12 @@ def _vec_sink(param):
 
 
 def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: float, relu, want_dres: bool,
-             group=None, beta=None, scratch=None, presums=None, presums_clear: bool = False):
+             group=None, beta=None, scratch=None, presums=None, presums_clear: bool = False, coef_only: bool = False):
     """-> dy, dres (or None), dgamma, dbeta.
+
+    ``coef_only`` (with ``presums``): no pass over the tensors at all - the first result is the fp32 ``[5, C]``
+    coefficient table (rows A, B, K of ``dy = A*dout + B*y + K``, then scale, shift) for a kernel that applies it on
+    the fly (``conv.bottleneck_tail_bwd``).
 
     ``presums`` (fp32 ``[2, rows, C]``: partial sums of ``dout`` and of ``dout*y``, as returned by
     ``conv.dgrad_gpu(..., bn_sums=True)``) replaces this function's own reduction pass over dout and y;
@@ -283,6 +287,16 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
         _lib.check(l.pda_bn_bwd_coefs(tot[0].data_ptr(), tot[1].data_ptr(), C, mean.data_ptr(), invstd.data_ptr(),
                                       scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma), float(count),
                                       coef.data_ptr(), _lib.stream()), "pda_bn_bwd_coefs")
+    if coef_only:
+        if presums is None or want_dres:
+            raise ValueError("norm.backward: coef_only needs presums and has no residual gradient to write")
+        if direct:
+            for p in (gamma, beta):
+                cb = getattr(p, "_pda_grad_ready", None)
+                if cb is not None:
+                    cb()
+            return coef, None, None, None
+        return coef, None, dgb[0], dgb[1]
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     if cap is not None:
