@@ -47,7 +47,7 @@ _SIGS = {
     "pda_conv_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
     "pda_bottleneck_tail_bwd_rows": [c_ll],
-    "pda_bottleneck_tail_bwd": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
+    "pda_bottleneck_tail_bwd": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_conv_pw_bm": [c_i],
     "pda_conv_pw_fprop": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i,
                           c_i, c_i, c_i, c_p],

@@ -360,32 +360,39 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
 
 
 def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, x2: torch.Tensor, in_affine: tuple,
-                        w_crsk: torch.Tensor, dw: torch.Tensor):
-    """BatchNorm backward apply + dgrad + wgrad of a bottleneck's last 1x1 conv (64 -> 256 channels) in one pass
+                        w_crsk: torch.Tensor, dw: Optional[torch.Tensor]):
+    """BatchNorm backward apply + dgrad (+ wgrad) of a bottleneck's last 1x1 conv in one pass
     (``csrc/kernels/bottleneck_tail_bwd.hip``): ``dy3 = coef[0]*dz + coef[1]*y3 + coef[2]`` is formed per 64-pixel
-    tile on chip, ``dx = (dy3 @ W) * (a2 > 0)`` with ``a2 = relu(x2*scale + shift)``, ``dw += dy3^T @ a2`` (fp32
-    ``[256,1,1,64]``, accumulated with atomics).  Returns ``(dx, sums)`` with ``sums`` = fp32 ``[2, rows, 64]``
-    partial sums of ``dx`` and ``dx*x2`` (the reductions of the producing BatchNorm's backward), or ``None`` when
-    the shapes are not the ones the kernel is built for."""
+    tile on chip, ``dx = (dy3 @ W) * (a2 > 0)`` with ``a2 = relu(x2*scale + shift)``.
+
+    64 -> 256 channels: also ``dw += dy3^T @ a2`` (fp32 ``[256,1,1,64]``, accumulated with atomics); ``dy3`` is never
+    stored.  128 -> 512 channels: ``dw`` is ``None`` and ``dy3`` is returned for a separate weight-gradient kernel.
+    Returns ``(dx, sums, dy3 or None)`` with ``sums`` = fp32 ``[2, rows, Ci]`` partial sums of ``dx`` and ``dx*x2``
+    (the reductions of the producing BatchNorm's backward), or ``None`` for other shapes."""
     l = _lib.lib()
     Co, Ci = y3.shape[-1], x2.shape[-1]
     M = y3.numel() // Co
-    if (Ci != 64 or Co != 256 or y3.element_size() != 2 or dz.shape != y3.shape or dz.dtype != y3.dtype
-            or x2.dtype != y3.dtype or x2.numel() != M * Ci or coef.dtype != torch.float32 or coef.shape[-1] != Co
-            or coef.shape[0] < 3 or not coef.is_contiguous() or dw.dtype != torch.float32 or dw.numel() != Co * Ci
-            or not dw.is_contiguous() or tuple(w_crsk.shape) != (Ci, 1, 1, Co) or w_crsk.dtype != y3.dtype
+    if ((Ci, Co) not in ((64, 256), (128, 512)) or y3.element_size() != 2 or dz.shape != y3.shape
+            or dz.dtype != y3.dtype or x2.dtype != y3.dtype or x2.numel() != M * Ci or coef.dtype != torch.float32
+            or coef.shape[-1] != Co or coef.shape[0] < 3 or not coef.is_contiguous()
+            or tuple(w_crsk.shape) != (Ci, 1, 1, Co) or w_crsk.dtype != y3.dtype
             or not (dz.is_contiguous() and y3.is_contiguous() and x2.is_contiguous() and w_crsk.is_contiguous())):
+        return None
+    with_wgrad = Ci == 64
+    if with_wgrad and (dw is None or dw.dtype != torch.float32 or dw.numel() != Co * Ci or not dw.is_contiguous()):
         return None
     rows = l.pda_bottleneck_tail_bwd_rows(M)
     dx = torch.empty_like(x2)
+    dy = None if with_wgrad else torch.empty_like(y3)
     sums = torch.empty((2, rows, Ci), device=y3.device, dtype=torch.float32)
     rc = l.pda_bottleneck_tail_bwd(_lib.dt(y3), dz.data_ptr(), y3.data_ptr(), coef.data_ptr(), x2.data_ptr(),
                                    in_affine[0].data_ptr(), in_affine[1].data_ptr(), w_crsk.data_ptr(), dx.data_ptr(),
-                                   dw.data_ptr(), sums.data_ptr(), M, Ci, Co, _lib.stream())
+                                   dw.data_ptr() if with_wgrad else None, _lib.ptr(dy), sums.data_ptr(), M, Ci, Co,
+                                   _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_bottleneck_tail_bwd")
-    return dx, sums
+    return dx, sums, dy
 
 
 def krsc_to_crsk(w_krsc: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -73,7 +73,8 @@ _DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
 
 # Backward of a bottleneck's last 1x1 conv on the 64 -> 256 geometry: BatchNorm backward apply + dgrad + wgrad in one
 # pass over the 256-channel tensors (csrc/kernels/bottleneck_tail_bwd.hip) instead of three kernels and five passes.
-_FUSE_TAIL_BWD = os.environ.get("PDA_FUSE_TAIL_BWD", "1") == "1"
+# (0: off, 1: the 64 -> 256 geometry only, 2: also 128 -> 512, where the weight gradient stays a kernel of its own)
+_FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "2"))
 
 
 class BNBackwardLink:
@@ -212,28 +213,34 @@ class _ConvBnActFn(torch.autograd.Function):
             presums_clear = presums is not None and presums is ctx.out_link.sums_buf
             ctx.out_link.y = None
         link = ctx.in_link
+        tail_dx = None
+        geom_small = (K, Cin, R, S) == (256, 64, 1, 1)
         if (_FUSE_TAIL_BWD and train_stats and ctx.premasked and presums is not None and ctx.in_aff is not None
-                and (K, Cin, R, S) == (256, 64, 1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0)
-                and dout.element_size() == 2 and dout.dtype == x.dtype and y is not None and dalias is None
-                and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not backends.deterministic
+                and (geom_small or ((K, Cin, R, S) == (512, 128, 1, 1) and _FUSE_TAIL_BWD >= 2)) and tuple(stride) == (1, 1)
+                and tuple(pad) == (0, 0) and dout.element_size() == 2 and dout.dtype == x.dtype and y is not None
+                and dalias is None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
                 and link is not None and link.y is not None and link.y.data_ptr() == x.data_ptr() and link.relu
-                and link.remask and C.grad_sink(weight) is not None):
-            # BatchNorm backward apply, dgrad (with the producer's ReLU mask and BatchNorm sums) and wgrad in one pass:
-            # dy is formed per tile on chip and never stored
+                and link.remask
+                and (not geom_small or (C.grad_sink(weight) is not None and not backends.deterministic))):
+            # BatchNorm backward apply and dgrad (with the producer's ReLU mask and BatchNorm sums) in one pass over dout
+            # and y; on the 64 -> 256 geometry the wgrad too (dy is formed per tile on chip and never stored), on
+            # 128 -> 512 dy is also written for the weight-gradient kernel below
             coef, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False, False, group,
                                           ctx.beta, cache.stats_buffer(K, dout.device), presums=presums,
                                           presums_clear=presums_clear, coef_only=True)
             r = C.bottleneck_tail_bwd(dout.view(-1, K), y.view(-1, K), coef, x.view(-1, Cin), ctx.in_aff,
-                                      cache.transposed(weight, dout.dtype), C.grad_sink(weight))
+                                      cache.transposed(weight, dout.dtype), C.grad_sink(weight) if geom_small else None)
             if r is None:
                 raise RuntimeError("conv_bn_act: the fused bottleneck-tail backward refused a shape its caller checked")
-            dx, link.sums = r[0].view(x.shape), r[1]
-            C.notify_grad_ready(weight)
-            if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
-                dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-            return (dx, None, dg, db, dout if has_res else None, None, None, None, None, None, None, None, None, None,
-                    None)
-        if train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
+            tail_dx, link.sums = r[0].view(x.shape), r[1]
+            dres = dout if has_res else None
+            if geom_small:
+                C.notify_grad_ready(weight)
+                if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
+                    dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
+                return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None)
+            dy = r[2].view(y.shape)
+        elif train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)
             dy, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False,
@@ -269,7 +276,9 @@ class _ConvBnActFn(torch.autograd.Function):
                 streams.mark(dy.device)
                 C.notify_grad_ready(weight)
                 wgrad_done = True
-        if ctx.needs_input_grad[0]:
+        if tail_dx is not None:
+            dx = tail_dx
+        elif ctx.needs_input_grad[0]:
             if dalias is not None:
                 dalias = dalias.contiguous()
             # what this op does on behalf of the op that produced x (see BNBackwardLink)
