@@ -395,6 +395,31 @@ def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, 
     return dx, sums, dy
 
 
+def stem_bwd_fused(dact: torch.Tensor, y0: torch.Tensor, coef: torch.Tensor, xp: torch.Tensor, geom: tuple,
+                   stride_h: int) -> Optional[torch.Tensor]:
+    """BatchNorm backward apply + weight gradient of the ResNet stem in one pass (``csrc/kernels/stem_bwd.hip``):
+    ``dy0 = coef[0]*g + coef[1]*y0 + coef[2]`` with ``g = dact * (y0*coef[3] + coef[4] > 0)`` is formed per tile on
+    chip and multiplied into the gathered operand rows of ``xp`` (``geom``: the stem's implicit-GEMM geometry,
+    ``ops/fused.py::_stem_geometry``).  Returns the fp32 weight gradient ``[K, R, 1, 32]`` or ``None`` when the
+    geometry is not the 7-row, 64-filter stem in a 16-bit type."""
+    l = _lib.lib()
+    N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, R, S = geom
+    K = y0.shape[-1]
+    M = y0.numel() // K
+    if (K != 64 or R != 7 or S != 1 or Ci != 32 or y0.element_size() != 2 or dact.shape != y0.shape
+            or dact.dtype != y0.dtype or xp.dtype != y0.dtype or coef.dtype != torch.float32
+            or tuple(coef.shape) != (5, K) or not (dact.is_contiguous() and y0.is_contiguous() and xp.is_contiguous()
+                                                    and coef.is_contiguous()) or M != N * Ho * Wo):
+        return None
+    dw = torch.zeros((K, R, 1, 32), device=y0.device, dtype=torch.float32)
+    rc = l.pda_stem_bwd_fused(_lib.dt(y0), dact.data_ptr(), y0.data_ptr(), coef.data_ptr(), xp.data_ptr(),
+                              dw.data_ptr(), M, K, R, Ho, Wo, sn, sh, sw, stride_h, _lib.stream())
+    if rc < 0:
+        return None
+    _lib.check(rc, "pda_stem_bwd_fused")
+    return dw
+
+
 def krsc_to_crsk(w_krsc: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     l = _lib.lib()
     K, R, S, C = w_krsc.shape

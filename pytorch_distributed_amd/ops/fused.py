@@ -75,6 +75,8 @@ _DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
 # pass over the 256-channel tensors (csrc/kernels/bottleneck_tail_bwd.hip) instead of three kernels and five passes.
 # (0: off, 1: the 64 -> 256 geometry only, 2: also 128 -> 512, where the weight gradient stays a kernel of its own)
 _FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "2"))
+# Backward of the stem: BatchNorm backward apply + weight gradient in one pass (csrc/kernels/stem_bwd.hip).
+_FUSE_STEM_BWD = os.environ.get("PDA_FUSE_STEM_BWD", "1") == "1"
 
 
 class BNBackwardLink:
@@ -507,7 +509,17 @@ class _StemFn(torch.autograd.Function):
         dout = dout.contiguous()
         K, Cin, R, S = wshape
         dact = P.maxpool_bwd_gpu(dout, idx, act_shape, *pool) if pool is not None else dout
-        if train_stats:
+        if (train_stats and _FUSE_STEM_BWD and ctx.needs_input_grad[1] and dact.element_size() == 2
+                and (K, R) == (64, 7) and not backends.deterministic):
+            # BatchNorm backward apply + weight gradient in one pass: dy is formed per tile on chip, never stored
+            coef, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group,
+                                          ctx.beta, coef_only=True)
+            dwk = C.stem_bwd_fused(dact, y, coef, xp, geom, stride[0])
+            if dwk is not None:
+                dw = dwk.view(K, R, 8, 4)[:, :, :S, :Cin].permute(0, 3, 1, 2)
+                return None, dw, dg, db, None, None, None, None, None, None, None, None
+            dy = Nm.apply_backward_coefs(dact, y, coef, True)
+        elif train_stats:
             dy, _, dg, db = Nm.backward(dact, y, None, mean_, invstd, scale, shift, gamma, count, True, False, group,
                                         ctx.beta)
         else:

@@ -226,7 +226,7 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
              group=None, beta=None, scratch=None, presums=None, presums_clear: bool = False, coef_only: bool = False):
     """-> dy, dres (or None), dgamma, dbeta.
 
-    ``coef_only`` (with ``presums``): no pass over the tensors at all - the first result is the fp32 ``[5, C]``
+    ``coef_only``: no apply pass (with ``presums`` no pass over the tensors at all) - the first result is the fp32 ``[5, C]``
     coefficient table (rows A, B, K of ``dy = A*dout + B*y + K``, then scale, shift) for a kernel that applies it on
     the fly (``conv.bottleneck_tail_bwd``).
 
@@ -288,8 +288,8 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                                       scale.data_ptr(), shift.data_ptr(), _lib.ptr(gamma), float(count),
                                       coef.data_ptr(), _lib.stream()), "pda_bn_bwd_coefs")
     if coef_only:
-        if presums is None or want_dres:
-            raise ValueError("norm.backward: coef_only needs presums and has no residual gradient to write")
+        if want_dres or cap is not None:
+            raise ValueError("norm.backward: coef_only has no residual gradient to write and knows no clipped ReLU")
         if direct:
             for p in (gamma, beta):
                 cb = getattr(p, "_pda_grad_ready", None)
@@ -314,6 +314,18 @@ def backward(dout, y, out_for_mask, mean, invstd, scale, shift, gamma, count: fl
                 cb()
         return dy, dres, None, None
     return dy, dres, dgb[0], dgb[1]
+
+
+def apply_backward_coefs(dout, y, coef, relu: bool = True):
+    """``dy = coef[0]*g + coef[1]*y + coef[2]`` (``g`` = ``dout`` masked by the ReLU recomputed from ``y`` when
+    ``relu``) for a coefficient table obtained with ``backward(..., coef_only=True)``: the apply pass on its own."""
+    l = _lib.lib()
+    C = y.shape[-1]
+    M = y.numel() // C
+    dy = torch.empty_like(y)
+    _lib.check(l.pda_bn_bwd_apply(_lib.dt(y), dout.data_ptr(), y.data_ptr(), None, coef.data_ptr(), M, C, int(relu),
+                                  dy.data_ptr(), None, _lib.stream()), "pda_bn_bwd_apply")
+    return dy
 
 
 class _BatchNormActFn(torch.autograd.Function):

@@ -633,6 +633,27 @@ def test_stem_matches_reference(dtype, hw):
     assert rel_err(m.bn1.weight.grad, ref.bn1.weight.grad) < 5 * TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 64, 64), (3, 50, 38), (9, 32, 32)])
+def test_stem_backward_fused_matches_separate_kernels(shape, dtype, monkeypatch):
+    """BatchNorm backward apply + stem weight gradient in one pass (stem_bwd.hip) against the two separate kernels:
+    same parameter gradients (dy itself is rounded identically, so only the summation order differs)."""
+    N, H, W = shape
+    torch.manual_seed(21)
+    m = models.resnet18().to(DEV).set_compute_dtype(dtype)
+    x = torch.randn(N, 3, H, W, device=DEV)
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(fused, "_FUSE_STEM_BWD", on)
+        m.zero_grad(set_to_none=True)
+        out = ops.stem_conv_bn_relu_pool(x, m.conv1.weight, m.bn1.weight, m.bn1.bias, (2, 2), (3, 3), m.bn1.state(), dtype)
+        g = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(3)).to(dtype)
+        out.backward(g)
+        grads.append((m.conv1.weight.grad.clone(), m.bn1.weight.grad.clone(), m.bn1.bias.grad.clone()))
+    for a_, b_ in zip(*grads):
+        assert rel_err(a_, b_) < 2e-3
+
+
 @pytest.mark.parametrize("arch,dtype,hw,batch", [("resnet18", torch.float32, 32, 8), ("resnet18", torch.float16, 32, 16),
                                                  ("resnet50", torch.float32, 64, 8), ("resnet50", torch.float16, 64, 32),
                                                  ("resnet50", torch.bfloat16, 64, 32)])
