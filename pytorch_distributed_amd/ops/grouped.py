@@ -1,20 +1,25 @@
-"""Grouped convolution: ResNeXt's 32-group 3x3 on the MFMA implicit-GEMM kernels, and depthwise
-convolution (one filter per channel) on its own vector-memory kernels (``csrc/kernels/depthwise_conv.hip``).
+"""Grouped convolution: ResNeXt's 32-group 3x3 on MFMA kernels, and depthwise convolution (one filter per
+channel) on its own vector-memory kernels (``csrc/kernels/depthwise_conv.hip``).
 
 A group of a ResNeXt layer is 4..32 channels wide: narrower than one MFMA tile, so a per-group GEMM would
-leave most of every matrix instruction idle and a scalar kernel would run at a few TFLOP/s.  On this
-hardware it is cheaper to spend the FLOPs: the grouped weight ``[K, C/groups, R, S]`` is expanded to its
-block-diagonal dense form ``[K, R, S, C]`` (zeros off the diagonal) and fprop / dgrad / wgrad run on the
-dense kernels at MFMA rate; the weight gradient is the block diagonal of the dense one.  The expansion
-costs ``groups`` times the useful FLOPs of the layer, which for ResNeXt-50 (32x4d) makes the whole network
-about 2.8x the MFMA work of ResNet-50 - still several times faster than scalar grouped kernels.  Meant
-for ``groups <= 64``.  A depthwise layer (``groups == in_channels == out_channels``) is bound by memory
-traffic instead and has dedicated fprop / dgrad / wgrad kernels.
+leave most of every matrix instruction idle and a scalar kernel would run at a few TFLOP/s.  The 3x3 layers
+with as many output as input channels per group (every grouped layer of the ResNeXt family) run on
+``csrc/kernels/grouped_conv.hip``: the channels are cut into chunks of 32 - whole groups - and each chunk is a
+dense 32 -> 32 convolution whose filter holds its groups on the diagonal, ``32 / Cg`` times the useful FLOPs
+(8x for 4-channel groups, none for 32-channel ones) on a layer that is bound by memory traffic anyway.
+
+Any other grouped shape (another filter size, fp32, groups wider than 32 channels) falls back to the dense
+kernels: the grouped weight ``[K, C/groups, R, S]`` is expanded to its block-diagonal dense form
+``[K, R, S, C]`` and the weight gradient is the block diagonal of the dense one, at ``groups`` times the useful
+FLOPs.  Meant for ``groups <= 64``.  A depthwise layer (``groups == in_channels == out_channels``) is bound by
+memory traffic instead and has dedicated fprop / dgrad / wgrad kernels.
 
 Reference role: ``torchvision.models.resnext*`` behind the reference's ``--arch`` switch
 (/root/reference/1.dataparallel.py:23-24,97-102); the CPU path is ``F.conv2d(groups=...)``.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn.functional as F
@@ -43,6 +48,106 @@ def block_diagonal(dw_dense: torch.Tensor, groups: int) -> torch.Tensor:
     idx = torch.arange(groups, device=dw_dense.device)
     d = dw_dense.view(groups, Kg, R, S, groups, Cg)[idx, :, :, :, idx, :]
     return d.reshape(K, R, S, Cg).permute(0, 3, 1, 2)
+
+
+_CHUNK_COLUMNS: dict = {}
+
+
+def _chunk_columns(Cg: int, device) -> torch.Tensor:
+    """``[32, Cg]``: for output channel ``o`` of a 32-channel chunk, the chunk-local input channels of its group."""
+    key = (Cg, str(device))
+    idx = _CHUNK_COLUMNS.get(key)
+    if idx is None:
+        o = torch.arange(32, device=device)
+        idx = ((o // Cg) * Cg).view(32, 1) + torch.arange(Cg, device=device).view(1, Cg)
+        _CHUNK_COLUMNS[key] = idx
+    return idx
+
+
+def chunk_filters(w_kcrs: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Logical ``[K, Cg, R, S]`` (``K`` a multiple of 32, ``Cg`` dividing 32) -> ``[K/32, 32, R*S, 32]``: per
+    chunk of 32 channels the dense ``[output][tap][input]`` filter with the chunk's groups on the diagonal."""
+    K, Cg, R, S = w_kcrs.shape
+    nch = K // 32
+    w = w_kcrs.detach().to(dtype).permute(0, 2, 3, 1).reshape(nch, 32, R * S, Cg)
+    out = torch.zeros((nch, 32, R * S, 32), device=w.device, dtype=dtype)
+    idx = _chunk_columns(Cg, w.device).view(1, 32, 1, Cg).expand(nch, 32, R * S, Cg)
+    return out.scatter_(3, idx, w)
+
+
+def chunk_diagonal(dwc: torch.Tensor, Cg: int, R: int, S: int) -> torch.Tensor:
+    """``[K/32, 32, R*S, 32]`` -> logical ``[K, Cg, R, S]`` (the part that belongs to the groups)."""
+    nch = dwc.shape[0]
+    idx = _chunk_columns(Cg, dwc.device).view(1, 32, 1, Cg).expand(nch, 32, R * S, Cg)
+    return dwc.gather(3, idx).reshape(nch * 32, R, S, Cg).permute(0, 3, 1, 2)
+
+
+def _chunked_ok(x: torch.Tensor, weight: torch.Tensor, stride, pad, groups: int) -> bool:
+    K, Cg, R, S = weight.shape
+    N, Hi, Wi, Cc = x.shape
+    return (x.element_size() == 2 and R == 3 and S == 3 and K == Cc and K % 32 == 0 and 32 % Cg == 0
+            and stride[0] == stride[1] and stride[0] in (1, 2) and pad[0] == pad[1] and 0 <= pad[0] <= 2
+            and max(Hi, Wi) < 512 and x.numel() * 2 < 2 ** 31 - 1 and os.environ.get("PDA_GROUPED_DENSE", "0") != "1")
+
+
+class _ChunkedGroupedConvFn(torch.autograd.Function):
+    """3x3 grouped convolution with ``Cg`` input and output channels per group on the 32-channel-chunk kernels."""
+
+    @staticmethod
+    def _conv(mode, src, wc, out_shape, stride, pad):
+        l = _lib.lib()
+        N, Hs, Ws, Cc = src.shape
+        out = torch.empty(out_shape, device=src.device, dtype=src.dtype)
+        _lib.check(l.pda_grouped_conv3x3(_lib.dt(src), mode, src.data_ptr(), wc.data_ptr(), out.data_ptr(), N, Hs, Ws,
+                                         out_shape[1], out_shape[2], Cc, stride, pad, _lib.stream()),
+                   "pda_grouped_conv3x3")
+        return out
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        x = x.contiguous()
+        K = weight.shape[0]
+        N, Hi, Wi, _ = x.shape
+        Ho, Wo = C.out_size(Hi, 3, stride[0], pad[0]), C.out_size(Wi, 3, stride[1], pad[1])
+        if Ho < 1 or Wo < 1:
+            raise ValueError(f"grouped conv: a 3x3 window does not fit a {Hi}x{Wi} input with padding {pad}")
+        wc = chunk_filters(weight, x.dtype)
+        y = _ChunkedGroupedConvFn._conv(0, x, wc, (N, Ho, Wo, K), stride[0], pad[0])
+        if bias is not None:
+            l = _lib.lib()
+            _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), K,
+                                      0, _lib.stream()), "pda_bias_add")
+        ctx.save_for_backward(x, weight)
+        ctx.wc = wc
+        ctx.cfg = (stride, pad, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import backends
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        K, Cg, R, S = weight.shape
+        N, Hi, Wi, _ = x.shape
+        l = _lib.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx = sum over taps of dy * W^T: the same kernel with each chunk's [output][tap][input] filter transposed
+            dx = _ChunkedGroupedConvFn._conv(1, dy, ctx.wc.transpose(1, 3).contiguous(), tuple(x.shape), stride[0],
+                                             pad[0])
+        if ctx.needs_input_grad[1]:
+            dwc = torch.zeros((K // 32, 32, 9, 32), device=dy.device, dtype=torch.float32)
+            _lib.check(l.pda_grouped_conv3x3_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dwc.data_ptr(), N, Hi, Wi,
+                                                   dy.shape[1], dy.shape[2], K, stride[0], pad[0], _lib.stream()),
+                       "pda_grouped_conv3x3_wgrad")
+            dw = chunk_diagonal(dwc, Cg, R, S).to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(K, device=dy.device, dtype=torch.float32)
+            _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // K, K,
+                                    int(backends.deterministic), _lib.stream()),
+                       "pda_colsum")
+        return dx, dw, db, None, None
 
 
 class _GroupedConvFn(torch.autograd.Function):
@@ -151,4 +256,7 @@ def grouped_conv2d(x: torch.Tensor, weight: torch.Tensor, bias, stride, pad, gro
     if groups > MAX_GROUPS:
         raise NotImplementedError(f"grouped conv with {groups} groups of {weight.shape[1]} channels has no kernel "
                                   f"here (supported: depthwise, or at most {MAX_GROUPS} groups)")
+    from .. import backends
+    if _chunked_ok(x, weight, tuple(stride), tuple(pad), groups) and not backends.deterministic:
+        return _ChunkedGroupedConvFn.apply(x, weight, bias, tuple(stride), tuple(pad))
     return _GroupedConvFn.apply(x, weight, bias, tuple(stride), tuple(pad), groups)

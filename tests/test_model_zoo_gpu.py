@@ -105,7 +105,8 @@ def test_ceil_mode_and_avg_pools_gpu():
 @pytest.mark.parametrize("cin,cout,groups,stride,bias", [(128, 128, 32, 1, False), (256, 256, 32, 2, False),
                                                         (64, 128, 8, 1, True)])
 def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
-    """Block-diagonal expansion on the MFMA kernels == F.conv2d(groups=...) in fp32."""
+    """Grouped convolution (the 32-channel-chunk kernels for the 16-bit square layers, block-diagonal expansion on the
+    dense MFMA kernels for the others) == F.conv2d(groups=...) in fp32."""
     torch.manual_seed(8)
     x = torch.randn(4, 14, 14, cin, device=DEV, dtype=dtype, requires_grad=True)
     w = (torch.randn(cout, cin // groups, 3, 3, device=DEV) * 0.1).requires_grad_(True)
@@ -129,6 +130,48 @@ def test_grouped_conv_matches_reference(dtype, cin, cout, groups, stride, bias):
     assert w.grad.shape == wr.grad.shape and rel(w.grad, wr.grad) < tol
     if bias:
         assert rel(b.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ch,cg,stride,n,h,w", [(128, 4, 1, 3, 56, 56), (256, 8, 2, 2, 56, 56), (512, 16, 1, 5, 14, 14),
+                                                (1024, 32, 2, 3, 14, 14), (1024, 32, 1, 5, 7, 7), (160, 8, 1, 2, 13, 20),
+                                                (96, 4, 2, 3, 15, 9), (64, 16, 1, 1, 5, 150), (128, 32, 2, 2, 9, 140)])
+def test_grouped_conv_chunk_kernels(dtype, ch, cg, stride, n, h, w):
+    """The 32-channel-chunk kernels of ResNeXt's grouped 3x3 (fprop / dgrad without LDS, filter in registers; wgrad
+    through transposing LDS reads of a halo tile) == F.conv2d(groups=...) in fp32, and == the dense block-diagonal
+    fallback; the native entry points must have taken the call."""
+    from pytorch_distributed_amd.ops import grouped as G
+    torch.manual_seed(18)
+    groups = ch // cg
+    x = torch.randn(n, h, w, ch, device=DEV, dtype=dtype, requires_grad=True)
+    wt = (torch.randn(ch, cg, 3, 3, device=DEV) * 0.1).requires_grad_(True)
+    assert G._chunked_ok(x, wt, (stride, stride), (1, 1), groups)
+    y = ops.conv2d(x, wt, None, (stride, stride), (1, 1), groups=groups)
+    assert y.grad_fn.name().startswith("_ChunkedGroupedConvFn")
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = wt.detach().to(dtype).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=stride, padding=1, groups=groups)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+
+    def rel(a, r):
+        a, r = a.detach().float(), r.detach()
+        return float((a - r).norm() / (r.norm() + 1e-30))
+    assert y.shape == yr.permute(0, 2, 3, 1).shape
+    assert rel(y, yr.permute(0, 2, 3, 1)) < tol
+    g = torch.randn_like(yr)
+    y.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+    yr.backward(g.to(dtype).float())
+    assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
+    assert wt.grad.shape == wr.grad.shape and rel(wt.grad, wr.grad) < tol
+    # element-wise against the dense fallback on the same 16-bit inputs
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = wt.detach().clone().requires_grad_(True)
+    y2 = G._GroupedConvFn.apply(x2, w2, None, (stride, stride), (1, 1), groups)
+    y2.backward(g.permute(0, 2, 3, 1).to(dtype).contiguous())
+    atol = 2e-2 if dtype == torch.float16 else 1.5e-1
+    assert torch.allclose(y.float(), y2.float(), atol=atol, rtol=2e-2)
+    assert torch.allclose(x.grad.float(), x2.grad.float(), atol=atol, rtol=2e-2)
+    assert rel(wt.grad, w2.grad) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
