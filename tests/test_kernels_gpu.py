@@ -984,10 +984,13 @@ def test_ddp_single_rank_rccl_matches_plain_model(tmp_path, backend):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
-def test_graphed_step_trains(precision):
+def test_graphed_step_trains(precision, monkeypatch):
     """A whole step (zero_grad, forward, loss, scaled backward, fused SGD) recorded into a hipGraph
     keeps training when replayed: same loss trajectory as the eager loop from the same start."""
     from pytorch_distributed_amd import amp
+    # (the fused stem backward adds its weight gradient with float atomics: two runs differ in the last bits, and this
+    # trajectory - the loss falls 100x in four steps - amplifies that to tens of percent by step 4)
+    monkeypatch.setattr(fused, "_FUSE_STEM_BWD", False)
     from pytorch_distributed_amd.optim import FusedSGD
     from pytorch_distributed_amd.utils.graph import GraphedStep
 
