@@ -29,6 +29,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -41,6 +42,9 @@ long long pda_shm_all_reduce_async(void* h, void* buf, long long count, int dtyp
 long long pda_shm_broadcast_async(void* h, void* buf, long long bytes, int root);
 long long pda_shm_all_gather_async(void* h, const void* in, void* out, long long bytes);
 int pda_shm_wait(void* h, long long ticket);
+int pda_store_set(void* h, const char* key, const void* val, int len);
+long long pda_store_get(void* h, const char* key, void* out, long long cap, long long timeout_ms);
+int pda_store_delete(void* h, const char* key);
 }
 
 namespace {
@@ -56,6 +60,237 @@ size_t dsize(int dt) {
     default: return 8;
   }
 }
+
+// What the engine exchanges through: the negotiation lists of every cycle and the host tensors.
+struct Transport {
+  virtual ~Transport() {}
+  virtual bool all_gather(const void* in, void* out, long long bytes) = 0;   // out: world * bytes, in rank order
+  virtual bool all_reduce(void* buf, long long count, int dtype, int op) = 0;
+  virtual bool broadcast(void* buf, long long bytes, int root) = 0;
+  virtual const char* what() const = 0;
+  // every rank's byte string, in rank order (the negotiation lists): lengths first, then the padded strings
+  virtual bool gather_strings(const std::string& mine, std::vector<std::string>* all, int world) {
+    long long n = (long long)mine.size();
+    std::vector<long long> lens((size_t)world);
+    if (!all_gather(&n, lens.data(), 8)) return false;
+    long long m = 1;
+    for (long long l : lens) m = std::max(m, l);
+    std::string pad = mine;
+    pad.resize((size_t)m, '\0');
+    std::string out((size_t)m * (size_t)world, '\0');
+    if (!all_gather(pad.data(), &out[0], m)) return false;
+    all->clear();
+    for (int r = 0; r < world; ++r) all->push_back(out.substr((size_t)r * (size_t)m, (size_t)lens[(size_t)r]));
+    return true;
+  }
+};
+
+// One node: the shared-memory communicator.
+struct ShmTransport : Transport {
+  explicit ShmTransport(void* shm) : shm_(shm) {}
+  bool all_gather(const void* in, void* out, long long bytes) override {
+    return pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, in, out, bytes)) == 0;
+  }
+  bool all_reduce(void* buf, long long count, int dtype, int op) override {
+    return pda_shm_wait(shm_, pda_shm_all_reduce_async(shm_, buf, count, dtype, op)) == 0;
+  }
+  bool broadcast(void* buf, long long bytes, int root) override {
+    return pda_shm_wait(shm_, pda_shm_broadcast_async(shm_, buf, bytes, root)) == 0;
+  }
+  const char* what() const override { return "shared-memory"; }
+  void* shm_;
+};
+
+float half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+  uint32_t u;
+  if (exp == 0) {
+    if (man == 0) u = sign;
+    else {
+      int e = -1;
+      uint32_t m = man;
+      do { ++e; m <<= 1; } while ((m & 0x400) == 0);
+      u = sign | (uint32_t)(127 - 15 - e) << 23 | (m & 0x3ff) << 13;
+    }
+  } else if (exp == 31) u = sign | 0x7f800000u | man << 13;
+  else u = sign | (exp + 112) << 23 | man << 13;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+uint16_t float_to_half(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000;
+  const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+  uint32_t man = u & 0x7fffff;
+  if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00 | (man ? 0x200 : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7c00);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    man |= 0x800000;
+    const int shift = 14 - exp;
+    uint32_t r = man >> shift;
+    const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = (uint32_t)exp << 10 | man >> 13;
+  const uint32_t rem = man & 0x1fff;
+  if (rem > 0x1000 || (rem == 0x1000 && (r & 1))) ++r;
+  return (uint16_t)(sign | r);
+}
+float bf16_to_float(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+uint16_t float_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffff) > 0x7f800000) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fff + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename A> A combine(A a, A b, int op) {
+  switch (op) {
+    case 1: return a * b;
+    case 2: return b < a ? b : a;
+    case 3: return b > a ? b : a;
+    default: return a + b;   // sum, average
+  }
+}
+template <typename T> void reduce_typed(T* dst, const T* all, long long count, int world, int op) {
+  for (long long i = 0; i < count; ++i) {
+    T acc = all[i];
+    for (int r = 1; r < world; ++r) acc = combine<T>(acc, all[(size_t)r * (size_t)count + (size_t)i], op);
+    if (op == 4) acc = (T)(acc / (T)world);
+    dst[i] = acc;
+  }
+}
+template <typename L, typename S> void reduce_16(uint16_t* dst, const uint16_t* all, long long count, int world, int op,
+                                                 L load, S store) {
+  for (long long i = 0; i < count; ++i) {
+    float acc = load(all[i]);
+    for (int r = 1; r < world; ++r) acc = combine<float>(acc, load(all[(size_t)r * (size_t)count + (size_t)i]), op);
+    if (op == 4) acc /= (float)world;
+    dst[i] = store(acc);
+  }
+}
+
+// Several nodes: everything goes through the key-value store of the rendezvous (a TCP client of this engine's own,
+// so that the engine thread never shares a socket with the rank's main thread).  An exchange is one `set` of the
+// rank's own value and one blocking `get` per peer; a rank deletes its keys of exchange n once exchange n + 1 is
+// complete, when every peer has read them.  This carries the negotiation lists (tens of bytes per cycle) and the
+// occasional host tensor; device tensors travel over RCCL from the executor.
+struct StoreTransport : Transport {
+  StoreTransport(void* store, const char* prefix, int rank, int world, long long timeout_ms)
+      : store_(store), prefix_(prefix), rank_(rank), world_(world), timeout_ms_(timeout_ms) {}
+  static constexpr long long kPiece = 8 << 20;
+
+  std::string key(long long seq, int rank, long long piece) const {
+    return prefix_ + "/" + std::to_string(seq) + "/" + std::to_string(rank) + "/" + std::to_string(piece);
+  }
+  bool all_gather(const void* in, void* out, long long bytes) override {
+    const long long seq = ++seq_;
+    std::vector<std::string> mine;
+    for (long long off = 0, piece = 0; off < bytes || piece == 0; off += kPiece, ++piece) {
+      const long long n = std::max<long long>(0, std::min(kPiece, bytes - off));
+      const std::string k = key(seq, rank_, piece);
+      if (pda_store_set(store_, k.c_str(), static_cast<const char*>(in) + off, (int)n) != 0) return false;
+      mine.push_back(k);
+      for (int r = 0; r < world_; ++r) {
+        char* dst = static_cast<char*>(out) + (size_t)r * (size_t)bytes + (size_t)off;
+        if (r == rank_) {
+          memcpy(dst, static_cast<const char*>(in) + off, (size_t)n);
+          continue;
+        }
+        if (pda_store_get(store_, key(seq, r, piece).c_str(), dst, n, timeout_ms_) != n) return false;
+      }
+    }
+    for (auto& k : prev_) pda_store_delete(store_, k.c_str());
+    prev_.swap(mine);
+    return true;
+  }
+  bool all_reduce(void* buf, long long count, int dtype, int op) override {
+    const size_t es = dtype == 0 || dtype == 5 ? 4 : (dtype == 1 || dtype == 2 ? 2 : (dtype == 3 ? 1 : 8));
+    // in slices, so that the gathered copy stays small
+    const long long slice = std::max<long long>(1, (16 << 20) / (long long)es / world_);
+    for (long long lo = 0; lo < count; lo += slice) {
+      const long long n = std::min(slice, count - lo);
+      char* p = static_cast<char*>(buf) + (size_t)lo * es;
+      scratch_.resize((size_t)n * es * (size_t)world_);
+      if (!all_gather(p, scratch_.data(), n * (long long)es)) return false;
+      switch (dtype) {
+        case 0: reduce_typed((float*)p, (const float*)scratch_.data(), n, world_, op); break;
+        case 4: reduce_typed((double*)p, (const double*)scratch_.data(), n, world_, op); break;
+        case 5: reduce_typed((int32_t*)p, (const int32_t*)scratch_.data(), n, world_, op); break;
+        case 6: reduce_typed((int64_t*)p, (const int64_t*)scratch_.data(), n, world_, op); break;
+        case 3: reduce_typed((uint8_t*)p, (const uint8_t*)scratch_.data(), n, world_, op); break;
+        case 1: reduce_16((uint16_t*)p, (const uint16_t*)scratch_.data(), n, world_, op, half_to_float, float_to_half); break;
+        case 2: reduce_16((uint16_t*)p, (const uint16_t*)scratch_.data(), n, world_, op, bf16_to_float, float_to_bf16); break;
+        default: return false;
+      }
+    }
+    return true;
+  }
+  bool broadcast(void* buf, long long bytes, int root) override {
+    const long long seq = ++seq_;
+    std::vector<std::string> mine;
+    for (long long off = 0, piece = 0; off < bytes; off += kPiece, ++piece) {
+      const long long n = std::min(kPiece, bytes - off);
+      const std::string k = key(seq, root, piece);
+      if (rank_ == root) {
+        if (pda_store_set(store_, k.c_str(), static_cast<const char*>(buf) + off, (int)n) != 0) return false;
+        mine.push_back(k);
+      } else if (pda_store_get(store_, k.c_str(), static_cast<char*>(buf) + off, n, timeout_ms_) != n) {
+        return false;
+      }
+    }
+    // the root may only delete once every peer has read: the one-byte exchange below is that acknowledgement
+    char ack = 1;
+    std::vector<char> acks((size_t)world_);
+    if (!all_gather(&ack, acks.data(), 1)) return false;
+    for (auto& k : mine) pda_store_delete(store_, k.c_str());
+    return true;
+  }
+  const char* what() const override { return "store"; }
+  // a stored value carries its own length: one exchange instead of two
+  bool gather_strings(const std::string& mine, std::vector<std::string>* all, int world) override {
+    const long long seq = ++seq_;
+    const std::string k = key(seq, rank_, 0);
+    if (pda_store_set(store_, k.c_str(), mine.data(), (int)mine.size()) != 0) return false;
+    all->assign((size_t)world, std::string());
+    std::vector<char> buf(1 << 16);
+    for (int r = 0; r < world; ++r) {
+      if (r == rank_) {
+        (*all)[(size_t)r] = mine;
+        continue;
+      }
+      const std::string kr = key(seq, r, 0);
+      long long n = pda_store_get(store_, kr.c_str(), buf.data(), (long long)buf.size(), timeout_ms_);
+      if (n > (long long)buf.size()) {
+        buf.resize((size_t)n);
+        n = pda_store_get(store_, kr.c_str(), buf.data(), (long long)buf.size(), timeout_ms_);
+      }
+      if (n < 0) return false;
+      (*all)[(size_t)r].assign(buf.data(), (size_t)n);
+    }
+    for (auto& p : prev_) pda_store_delete(store_, p.c_str());
+    prev_.assign(1, k);
+    return true;
+  }
+
+  void* store_;
+  std::string prefix_;
+  int rank_, world_;
+  long long timeout_ms_;
+  long long seq_ = 0;
+  std::vector<std::string> prev_;
+  std::vector<char> scratch_;
+};
 
 struct Request {
   long long handle;
@@ -77,8 +312,8 @@ typedef int (*ExecFn)(int kind, int n, const long long* handles, int op, int roo
 
 class Engine {
  public:
-  Engine(void* shm, int rank, int world, long long fusion_bytes, double cycle_ms, ExecFn exec)
-      : shm_(shm), rank_(rank), world_(world), fusion_bytes_(fusion_bytes), cycle_ms_(cycle_ms), exec_(exec) {
+  Engine(Transport* tr, int rank, int world, long long fusion_bytes, double cycle_ms, ExecFn exec)
+      : tr_(tr), rank_(rank), world_(world), fusion_bytes_(fusion_bytes), cycle_ms_(cycle_ms), exec_(exec) {
     fusion_.resize((size_t)std::max<long long>(fusion_bytes, 1 << 20));
     th_ = std::thread([this] { loop(); });
   }
@@ -149,18 +384,7 @@ class Engine {
   static void put(std::string& s, const void* p, size_t n) { s.append(static_cast<const char*>(p), n); }
 
   bool gather_bytes(const std::string& mine, std::vector<std::string>* all) {
-    long long n = (long long)mine.size();
-    std::vector<long long> lens((size_t)world_);
-    if (pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, &n, lens.data(), 8)) != 0) return false;
-    long long m = 1;
-    for (long long l : lens) m = std::max(m, l);
-    std::string pad = mine;
-    pad.resize((size_t)m, '\0');
-    std::string out((size_t)m * (size_t)world_, '\0');
-    if (pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, pad.data(), &out[0], m)) != 0) return false;
-    all->clear();
-    for (int r = 0; r < world_; ++r) all->push_back(out.substr((size_t)r * (size_t)m, (size_t)lens[(size_t)r]));
-    return true;
+    return tr_->gather_strings(mine, all, world_);
   }
 
   struct Meta { int kind, dtype, op, root, device; long long count; };
@@ -208,9 +432,9 @@ class Engine {
     if (grp.size() == 1) {  // large or lonely tensor: reduce in place
       Request& r = grp[0];
       scale_buf(r.ptr, r.count, dt, r.prescale, 0);
-      int rc = pda_shm_wait(shm_, pda_shm_all_reduce_async(shm_, r.ptr, r.count, dt, op));
+      int rc = tr_->all_reduce(r.ptr, r.count, dt, op) ? 0 : -1;
       scale_buf(r.ptr, r.count, dt, r.postscale, 0);
-      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-reduce failed");
+      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : std::string(tr_->what()) + " all-reduce failed");
       return;
     }
     size_t off = 0;
@@ -219,13 +443,13 @@ class Engine {
       scale_buf(&fusion_[off], r.count, dt, r.prescale, 0);
       off += (size_t)r.count * es;
     }
-    int rc = pda_shm_wait(shm_, pda_shm_all_reduce_async(shm_, fusion_.data(), (long long)(off / es), dt, op));
+    int rc = tr_->all_reduce(fusion_.data(), (long long)(off / es), dt, op) ? 0 : -1;
     off = 0;
     for (auto& r : grp) {
       scale_buf(&fusion_[off], r.count, dt, r.postscale, 0);
       memcpy(r.ptr, &fusion_[off], (size_t)r.count * es);
       off += (size_t)r.count * es;
-      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-reduce failed");
+      finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : std::string(tr_->what()) + " all-reduce failed");
     }
   }
 
@@ -260,8 +484,8 @@ class Engine {
       }
       if (r.kind == K_ALLGATHER) {
         if (r.device == 0) {
-          int rc = pda_shm_wait(shm_, pda_shm_all_gather_async(shm_, r.ptr, r.ptr_out, r.count * (long long)dsize(r.dtype)));
-          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory all-gather failed");
+          int rc = tr_->all_gather(r.ptr, r.ptr_out, r.count * (long long)dsize(r.dtype)) ? 0 : -1;
+          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : std::string(tr_->what()) + " all-gather failed");
         } else {
           std::vector<Request> g1{r};
           run_device_group(g1);
@@ -271,8 +495,8 @@ class Engine {
       }
       if (r.kind == K_BROADCAST) {
         if (r.device == 0) {
-          int rc = pda_shm_wait(shm_, pda_shm_broadcast_async(shm_, r.ptr, r.count * (long long)dsize(r.dtype), r.root));
-          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : "shared-memory broadcast failed");
+          int rc = tr_->broadcast(r.ptr, r.count * (long long)dsize(r.dtype), r.root) ? 0 : -1;
+          finish(r.handle, rc == 0 ? 1 : -1, rc == 0 ? "" : std::string(tr_->what()) + " broadcast failed");
         } else {
           std::vector<Request> g1{r};
           run_device_group(g1);
@@ -399,7 +623,7 @@ class Engine {
     cv_.notify_all();
   }
 
-  void* shm_;
+  std::unique_ptr<Transport> tr_;
   int rank_, world_;
   long long fusion_bytes_;
   double cycle_ms_;
@@ -419,7 +643,14 @@ class Engine {
 }  // namespace
 
 PDA_EXPORT void* pda_hvd_create(void* shm, int rank, int world, long long fusion_bytes, double cycle_ms, void* exec) {
-  return new Engine(shm, rank, world, fusion_bytes, cycle_ms, reinterpret_cast<ExecFn>(exec));
+  return new Engine(new ShmTransport(shm), rank, world, fusion_bytes, cycle_ms, reinterpret_cast<ExecFn>(exec));
+}
+// The same engine for ranks on several nodes: negotiation and host tensors through the key-value store `store` (a
+// client handle of store.cc that the engine thread has to itself), every key under `prefix`.
+PDA_EXPORT void* pda_hvd_create_store(void* store, const char* prefix, int rank, int world, long long fusion_bytes,
+                                      double cycle_ms, void* exec, long long timeout_ms) {
+  return new Engine(new StoreTransport(store, prefix, rank, world, timeout_ms), rank, world, fusion_bytes, cycle_ms,
+                    reinterpret_cast<ExecFn>(exec));
 }
 PDA_EXPORT void pda_hvd_shutdown(void* h) { static_cast<Engine*>(h)->shutdown(); }
 PDA_EXPORT void pda_hvd_destroy(void* h) { delete static_cast<Engine*>(h); }

@@ -18,8 +18,11 @@ tensor fusion) runs CPU tensors through the shared-memory backend and device ten
 executor that spends three launches on a fused group whatever its size: ONE multi-tensor pack into the
 persistent fusion buffer that also casts to the wire dtype (``Compression.fp16``) and applies the
 pre-scale, ONE all-reduce on this package's own RCCL communicator (or the peer-memory kernels with
-``PDA_HVD_DEVICE_COMM=p2p``), ONE multi-tensor unpack that casts back and applies average / post-scale;
-across hosts a synchronous ``torch.distributed`` path is used.
+``PDA_HVD_DEVICE_COMM=p2p``), ONE multi-tensor unpack that casts back and applies average / post-scale.
+With ranks on several hosts (``LOCAL_WORLD_SIZE < WORLD_SIZE``) the same engine runs with its control plane -
+the per-cycle negotiation lists, and host tensors - on a TCP key-value store of its own instead of the
+shared-memory segment (``StoreTransport`` in ``hvd_core.cc``); device tensors still go through the executor
+and RCCL.  ``PDA_HVD_MULTI_HOST_ENGINE=0`` selects synchronous ``torch.distributed`` collectives instead.
 """
 from __future__ import annotations
 
@@ -27,6 +30,7 @@ import atexit
 import ctypes
 import os
 import threading
+import time
 from typing import Dict, Optional
 
 import torch
@@ -43,6 +47,8 @@ _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.uint8: 3, to
 _runtime.register({
     "pda_hvd_create": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
                                          ctypes.c_double, ctypes.c_void_p]),
+    "pda_hvd_create_store": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_longlong, ctypes.c_double, ctypes.c_void_p, ctypes.c_longlong]),
     "pda_hvd_shutdown": (None, [ctypes.c_void_p]),
     "pda_hvd_destroy": (None, [ctypes.c_void_p]),
     "pda_hvd_enqueue": (ctypes.c_longlong, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
@@ -121,6 +127,7 @@ class _State:
         self.engine = None
         self.shm = None
         self.store = None
+        self.ctl_store = None   # several nodes: the engine thread's own client of the rendezvous store
         self.lib = None
         self.exec_cb = None
         self.handles: Dict[int, _Pending] = {}
@@ -150,7 +157,8 @@ def init(comm=None, process_sets=None) -> None:
     _S.initialized = True
     if info.world_size == 1:
         return
-    _S.multi_host = info.local_size < info.world_size
+    # (PDA_HVD_FORCE_MULTI_HOST=1: rehearse the several-node control plane with all ranks on one machine)
+    _S.multi_host = info.local_size < info.world_size or os.environ.get("PDA_HVD_FORCE_MULTI_HOST", "0") == "1"
     import torch.distributed as dist
     if not dist.is_initialized():
         from ..comm import init_process_group
@@ -158,16 +166,39 @@ def init(comm=None, process_sets=None) -> None:
                              and os.environ.get("PDA_HVD_NO_CUDA", "0") != "1") else "gloo"
         init_process_group(backend, "env://", info.world_size, info.rank)
     _S.torch_group_ready = True
+    if _S.multi_host and os.environ.get("PDA_HVD_MULTI_HOST_ENGINE", "1") != "1":
+        return   # synchronous torch.distributed collectives, no engine
+    _S.lib = _runtime.lib()
+    fusion = int(float(os.environ.get("HOROVOD_FUSION_THRESHOLD", str(64 << 20))))
+    cycle = float(os.environ.get("HOROVOD_CYCLE_TIME", "1.0"))
     if _S.multi_host:
+        # Ranks on several nodes (the reference's `horovodrun -H host1:4,host2:4`, /root/reference/5.run.sh:3): the
+        # same engine - name negotiation, fusion, the device executor - with its control plane on a TCP store
+        # instead of the shared-memory segment; device tensors travel over RCCL, which spans nodes by itself.
+        port = int(os.environ.get("PDA_HVD_PORT", str(info.master_port + 17)))
+        if info.rank == 0:
+            _S.store = TCPStore(info.master_addr, port, info.world_size, is_master=True)
+        _S.ctl_store = TCPStore(info.master_addr, port, info.world_size, is_master=False)
+        if (torch.cuda.is_available() and os.environ.get("PDA_HVD_DEVICE_COMM", "rccl") == "rccl"
+                and os.environ.get("PDA_HVD_NO_CUDA", "0") != "1"):
+            from ..comm import device_communicator
+            try:
+                device_communicator(torch.device("cuda", info.local_rank))
+            except Exception as e:  # noqa: BLE001 - torch.distributed's group remains as the device path
+                print(f"[hvd] rank {info.rank}: own RCCL communicator unavailable ({e}); using torch.distributed")
+        _S.exec_cb = _EXEC_T(_device_executor)
+        _S.engine = _S.lib.pda_hvd_create_store(_S.ctl_store._h, b"hvd/ctl", info.rank, info.world_size, fusion, cycle,
+                                                ctypes.cast(_S.exec_cb, ctypes.c_void_p),
+                                                int(float(os.environ.get("PDA_HVD_CTL_TIMEOUT_S", "300")) * 1000))
+        atexit.register(shutdown)
         return
-    # native engine: rendezvous for the shm segment goes through a store of its own
+    # one node: rendezvous for the shm segment goes through a store of its own
     from ..comm import native_store
     base = native_store()
     if base is None:
         port = int(os.environ.get("PDA_HVD_PORT", str(info.master_port + 17)))
         base = TCPStore(info.master_addr, port, info.world_size, is_master=(info.rank == 0))
         _S.store = base
-    _S.lib = _runtime.lib()
     _S.shm = ShmCommunicator(PrefixStore("hvd", base), info.rank, info.world_size, name="engine",
                              slot_bytes=int(os.environ.get("PDA_HVD_SHM_SLOT_BYTES", str(8 << 20))))
     if os.environ.get("PDA_HVD_DEVICE_COMM", "") == "p2p" and torch.cuda.is_available():
@@ -187,8 +218,6 @@ def init(comm=None, process_sets=None) -> None:
         except Exception as e:  # noqa: BLE001 - torch.distributed's group remains as the device path
             print(f"[hvd] rank {info.rank}: own RCCL communicator unavailable ({e}); using torch.distributed")
     _S.exec_cb = _EXEC_T(_device_executor)
-    fusion = int(float(os.environ.get("HOROVOD_FUSION_THRESHOLD", str(64 << 20))))
-    cycle = float(os.environ.get("HOROVOD_CYCLE_TIME", "1.0"))
     _S.engine = _S.lib.pda_hvd_create(_S.shm._h, info.rank, info.world_size, fusion, cycle,
                                       ctypes.cast(_S.exec_cb, ctypes.c_void_p))
     atexit.register(shutdown)
@@ -207,6 +236,24 @@ def shutdown() -> None:
     if _S.shm is not None:
         _S.shm.close()
         _S.shm = None
+    if _S.ctl_store is not None:
+        if _S.store is not None and _S.info is not None and _S.info.world_size > 1:
+            # the server lives in rank 0: it stays until every rank's engine has left its last exchange
+            try:
+                n = _S.ctl_store.add("hvd/ctl/left", 1)
+                deadline = time.time() + 30.0
+                while n < _S.info.world_size and time.time() < deadline:
+                    time.sleep(0.01)
+                    n = _S.ctl_store.add("hvd/ctl/left", 0)
+            except Exception:  # noqa: BLE001
+                pass
+        else:
+            try:
+                _S.ctl_store.add("hvd/ctl/left", 1)
+            except Exception:  # noqa: BLE001
+                pass
+        _S.ctl_store.close()
+        _S.ctl_store = None
     if _S.store is not None:
         _S.store.close()
         _S.store = None
@@ -288,9 +335,10 @@ def engine_stats() -> dict:
     """Engine counters: negotiation cycles, fused groups, and for device groups the number of device
     launches (pack + collective + unpack) spent on them."""
     if _S.engine is None:
-        return dict({"cycles": 0, "fused_groups": 0}, **_S.launch_stats)
+        return dict({"cycles": 0, "fused_groups": 0, "control_plane": "none"}, **_S.launch_stats)
     return dict({"cycles": int(_S.lib.pda_hvd_cycles(_S.engine)),
-                 "fused_groups": int(_S.lib.pda_hvd_fused_groups(_S.engine))}, **_S.launch_stats)
+                 "fused_groups": int(_S.lib.pda_hvd_fused_groups(_S.engine)),
+                 "control_plane": "store" if _S.ctl_store is not None else "shm"}, **_S.launch_stats)
 
 
 # ------------------------------------------------------------------------------- helpers
@@ -562,7 +610,7 @@ def _submit(kind: int, tensor: torch.Tensor, out: torch.Tensor, name: str, op: s
         if prescale != 1.0:
             wire.mul_(prescale)
         p.post, prescale, postscale = postscale, 1.0, 1.0
-    if _S.engine is None:  # multi-host fallback: synchronous torch.distributed
+    if _S.engine is None:  # no engine (PDA_HVD_MULTI_HOST_ENGINE=0 on several nodes): synchronous torch.distributed
         import torch.distributed as dist
         if kind == 1:
             dist.broadcast(wire, src=root)

@@ -154,6 +154,19 @@ def test_hvd_api_two_ranks():
     assert r.stdout.count("hvd OK") == 2
 
 
+def test_hvd_engine_with_store_control_plane():
+    """Ranks on several nodes: the same engine (name negotiation in any order, fusion, broadcast, all-gather, the
+    DistributedOptimizer) with its control plane and host tensors on the TCP store instead of shared memory -
+    rehearsed with both ranks on this machine."""
+    env = dict(os.environ, PDA_HVD_FORCE_MULTI_HOST="1")
+    r = subprocess.run([sys.executable, "-m", "pytorch_distributed_amd.launch", "-np", "2", "-H", "localhost:2",
+                        "--master_port", str(free_port()), os.path.join(ROOT, "tests", "workers", "hvd_worker.py")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("hvd OK") == 2
+    assert r.stdout.count("'control_plane': 'store'") == 2
+
+
 @pytest.mark.parametrize("kind", ["fused", "stock"])
 def test_hvd_with_amp_skips_overflowed_step_on_every_rank(kind):
     """scale_loss waits for the wrapper's reductions before its overflow pass: an infinity on one rank makes all

@@ -39,6 +39,20 @@ for i in range(3):
     loss = torch.nn.functional.nll_loss(net(x), y); loss.backward(); opt.step()
 chk = hvd.allreduce(net.fc2.weight.detach().clone(), name="chk2")
 assert torch.allclose(chk, net.fc2.weight, atol=1e-6), "replicas diverged"
+# a host tensor larger than one piece / slice of either control plane, and 16-bit host tensors
+gens = [torch.Generator().manual_seed(50 + i) for i in range(w)]
+big = [torch.randn(3_000_001, generator=g) for g in gens]
+got = hvd.allreduce(big[r].clone(), op=hvd.Sum, name="big")
+assert torch.allclose(got, sum(big), atol=1e-5), (got - sum(big)).abs().max()
+for dt in (torch.float16, torch.bfloat16):
+    vals = [(b[:4099] * 3).to(dt) for b in big]
+    got = hvd.allreduce(vals[r].clone(), op=hvd.Sum, name=f"half.{dt}")
+    exp = sum(v.float() for v in vals)
+    assert got.dtype == dt and torch.allclose(got.float(), exp, rtol=1e-2, atol=1e-2), (dt, (got.float() - exp).abs().max())
+    mx = hvd.allreduce(vals[r].clone(), op=hvd.Max, name=f"halfmax.{dt}")
+    assert torch.equal(mx, torch.stack(vals).max(0).values)
+ints = hvd.allreduce(torch.arange(10, dtype=torch.int64) * (r + 1), op=hvd.Sum, name="ints")
+assert torch.equal(ints, torch.arange(10, dtype=torch.int64) * sum(range(1, w + 1)))
 a = torch.tensor([1.0, 0.0]) if r == 0 else torch.tensor([0.0, 1.0])
 if w == 2:
     ad = hvd.allreduce(a, op=hvd.Adasum, name="ad"); assert torch.allclose(ad, torch.tensor([1.0, 1.0])), ad
