@@ -25,8 +25,8 @@ struct TailArgs {
   const void* y3;        // [M][256]
   const float* coef;     // [>=3][256]: A, B, K of BatchNorm3's backward
   const void* x2;        // [M][64] conv2's raw output (before BatchNorm2)
-  const void* in_scale;  // [64] of x2's type: a2 = relu(x2 * in_scale + in_shift)
-  const void* in_shift;
+  const void* in_scale;  // [64] of x2's type: a2 = relu(x2 * in_scale + in_shift); null: x2 is the activation itself,
+  const void* in_shift;  // dX is not masked and no sums are taken (a shortcut's 1x1 conv + BatchNorm)
   const void* wt;        // [64][256] transposed weight (CRSK)
   void* dx;              // [M][64]
   float* dw;             // [256][64] fp32, accumulated into (kernels with the weight gradient)
@@ -114,8 +114,12 @@ tail_bwd_kernel(TailArgs a) {
   // (the coefficients of a thread's eight channels are re-read from LDS per tile: 24 registers this kernel does not have)
   float* ctab = reinterpret_cast<float*>(lds + OFF_C);
   for (int i = t; i < 3 * CO; i += NT) ctab[i] = a.coef[i];
-  const frag xsc = *reinterpret_cast<const frag*>(reinterpret_cast<const T*>(a.in_scale) + cvx * 8);
-  const frag xsf = *reinterpret_cast<const frag*>(reinterpret_cast<const T*>(a.in_shift) + cvx * 8);
+  const bool plain = a.in_scale == nullptr;   // (uniform)
+  frag xsc = {}, xsf = {};
+  if (!plain) {
+    xsc = *reinterpret_cast<const frag*>(reinterpret_cast<const T*>(a.in_scale) + cvx * 8);
+    xsf = *reinterpret_cast<const frag*>(reinterpret_cast<const T*>(a.in_shift) + cvx * 8);
+  }
 
   // ---- MFMA roles.  dgrad (16x16x32): wave -> output columns cb * 16 .. + 15, pixel-row blocks rb0 .. rb0 + RBW - 1;
   // operand layout: lane -> row / column lane & 15, k = 8 * (lane >> 4) .. + 7 of a 32-deep step
@@ -196,7 +200,7 @@ tail_bwd_kernel(TailArgs a) {
     for (int v = 0; v < NVX; ++v) {
       okx[v] = m0 + rowx + RSX * v < a.M;
       x2raw[v] = x2v[v];
-      a2[v] = tail_affine_relu(__builtin_bit_cast(frag, x2v[v]), xsc, xsf);
+      a2[v] = plain ? __builtin_bit_cast(frag, x2v[v]) : tail_affine_relu(__builtin_bit_cast(frag, x2v[v]), xsc, xsf);
       if (!okx[v]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) a2[v][e] = 0;
@@ -245,7 +249,7 @@ tail_bwd_kernel(TailArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         // ReLU backward of the layer that produced a2: the mask is decided by the value the forward multiplied in
-        const bool pos = ElemTraits<T>::to_f32(a2[v][e]) > 0.f;
+        const bool pos = plain || ElemTraits<T>::to_f32(a2[v][e]) > 0.f;
         if (!pos) dxv.v[e] = ElemTraits<T>::from_f32(0.f);
         const float g = ElemTraits<T>::to_f32(dxv.v[e]);
         s1[v][e] += g;
@@ -267,6 +271,7 @@ tail_bwd_kernel(TailArgs a) {
       }
   }
   // ---- the producing BatchNorm's two sums: one row per workgroup
+  if (plain) return;   // (uniform)
   __syncthreads();
   float* red = reinterpret_cast<float*>(lds);
 #pragma unroll
@@ -301,7 +306,8 @@ PDA_EXPORT int pda_bottleneck_tail_bwd_rows(long long M) {
 // See the head of the file.  (Ci, Co) = (64, 256): dw (fp32 [256][64]) is accumulated into with float atomics (not for
 // the run-to-run reproducible mode) and dy may be null.  (Ci, Co) = (128, 512): dy ([M][512]) receives the BatchNorm
 // gradient for a separate weight-gradient kernel and dw is not touched.  Other geometries: <0, the caller runs the
-// separate kernels.  sums: [2][pda_bottleneck_tail_bwd_rows(M)][Ci].
+// separate kernels.  sums: [2][pda_bottleneck_tail_bwd_rows(M)][Ci].  in_scale == in_shift == null: x2 is the
+// activation itself (no transform, no mask on dx, no sums; sums may be null): a shortcut's 1x1 conv + BatchNorm.
 PDA_EXPORT int pda_bottleneck_tail_bwd(int dtype, const void* dz, const void* y3, const float* coef, const void* x2,
                                        const void* in_scale, const void* in_shift, const void* wt, void* dx, float* dw,
                                        void* dy, float* sums, long long M, int Ci, int Co, hipStream_t stream) {
@@ -313,7 +319,8 @@ PDA_EXPORT int pda_bottleneck_tail_bwd(int dtype, const void* dz, const void* y3
   if ((((uintptr_t)dz | (uintptr_t)y3 | (uintptr_t)x2 | (uintptr_t)in_scale | (uintptr_t)in_shift | (uintptr_t)wt |
         (uintptr_t)dx | (uintptr_t)dy) & 15) != 0)
     return -5;
-  if (!dz || !y3 || !coef || !x2 || !in_scale || !in_shift || !wt || !dx || !sums) return -11;
+  if (!dz || !y3 || !coef || !x2 || !wt || !dx) return -11;
+  if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale != nullptr && !sums)) return -11;
   if ((small && !dw) || (mid && !dy)) return -11;
   TailArgs a;
   a.dz = dz; a.y3 = y3; a.coef = coef; a.x2 = x2; a.in_scale = in_scale; a.in_shift = in_shift; a.wt = wt;

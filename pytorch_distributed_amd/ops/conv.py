@@ -359,8 +359,8 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
     return dw
 
 
-def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, x2: torch.Tensor, in_affine: tuple,
-                        w_crsk: torch.Tensor, dw: Optional[torch.Tensor]):
+def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, x2: torch.Tensor,
+                        in_affine: Optional[tuple], w_crsk: torch.Tensor, dw: Optional[torch.Tensor]):
     """BatchNorm backward apply + dgrad (+ wgrad) of a bottleneck's last 1x1 conv in one pass
     (``csrc/kernels/bottleneck_tail_bwd.hip``): ``dy3 = coef[0]*dz + coef[1]*y3 + coef[2]`` is formed per 64-pixel
     tile on chip, ``dx = (dy3 @ W) * (a2 > 0)`` with ``a2 = relu(x2*scale + shift)``.
@@ -368,7 +368,10 @@ def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, 
     64 -> 256 channels: also ``dw += dy3^T @ a2`` (fp32 ``[256,1,1,64]``, accumulated with atomics); ``dy3`` is never
     stored.  128 -> 512 channels: ``dw`` is ``None`` and ``dy3`` is returned for a separate weight-gradient kernel.
     Returns ``(dx, sums, dy3 or None)`` with ``sums`` = fp32 ``[2, rows, Ci]`` partial sums of ``dx`` and ``dx*x2``
-    (the reductions of the producing BatchNorm's backward), or ``None`` for other shapes."""
+    (the reductions of the producing BatchNorm's backward), or ``None`` for other shapes.
+
+    ``in_affine=None``: ``x2`` is the conv's input activation itself - ``dx = dy3 @ W`` unmasked, ``dw += dy3^T @ x2``,
+    ``sums`` is ``None`` (the 1x1 conv + BatchNorm of a shortcut branch)."""
     l = _lib.lib()
     Co, Ci = y3.shape[-1], x2.shape[-1]
     M = y3.numel() // Co
@@ -384,11 +387,12 @@ def bottleneck_tail_bwd(dz: torch.Tensor, y3: torch.Tensor, coef: torch.Tensor, 
     rows = l.pda_bottleneck_tail_bwd_rows(M)
     dx = torch.empty_like(x2)
     dy = None if with_wgrad else torch.empty_like(y3)
-    sums = torch.empty((2, rows, Ci), device=y3.device, dtype=torch.float32)
+    sums = None if in_affine is None else torch.empty((2, rows, Ci), device=y3.device, dtype=torch.float32)
     rc = l.pda_bottleneck_tail_bwd(_lib.dt(y3), dz.data_ptr(), y3.data_ptr(), coef.data_ptr(), x2.data_ptr(),
-                                   in_affine[0].data_ptr(), in_affine[1].data_ptr(), w_crsk.data_ptr(), dx.data_ptr(),
-                                   dw.data_ptr() if with_wgrad else None, _lib.ptr(dy), sums.data_ptr(), M, Ci, Co,
-                                   _lib.stream())
+                                   None if in_affine is None else in_affine[0].data_ptr(),
+                                   None if in_affine is None else in_affine[1].data_ptr(), w_crsk.data_ptr(),
+                                   dx.data_ptr(), dw.data_ptr() if with_wgrad else None, _lib.ptr(dy), _lib.ptr(sums), M,
+                                   Ci, Co, _lib.stream())
     if rc < 0:
         return None
     _lib.check(rc, "pda_bottleneck_tail_bwd")

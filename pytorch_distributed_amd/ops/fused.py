@@ -74,7 +74,7 @@ _DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
 # Backward of a bottleneck's last 1x1 conv on the 64 -> 256 geometry: BatchNorm backward apply + dgrad + wgrad in one
 # pass over the 256-channel tensors (csrc/kernels/bottleneck_tail_bwd.hip) instead of three kernels and five passes.
 # (0: off, 1: the 64 -> 256 geometry only, 2: also 128 -> 512, where the weight gradient stays a kernel of its own)
-_FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "2"))
+_FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "3"))   # 1: 64->256 tails, 2: + 128->512 tails, 3: + 64->256 shortcut
 # Backward of the stem: BatchNorm backward apply + weight gradient in one pass (csrc/kernels/stem_bwd.hip).
 _FUSE_STEM_BWD = os.environ.get("PDA_FUSE_STEM_BWD", "1") == "1"
 
@@ -242,6 +242,23 @@ class _ConvBnActFn(torch.autograd.Function):
                     dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
                 return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None)
             dy = r[2].view(y.shape)
+        elif (_FUSE_TAIL_BWD >= 3 and train_stats and geom_small and not relu and not has_res and not ctx.premasked
+              and ctx.out_link is None and link is None and ctx.in_aff is None and not ctx.mask_dx and dalias is None
+              and tuple(stride) == (1, 1) and tuple(pad) == (0, 0) and dout.element_size() == 2 and dout.dtype == x.dtype
+              and y is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+              and C.grad_sink(weight) is not None and not backends.deterministic):
+            # a 64 -> 256 shortcut (1x1 conv + BatchNorm, no activation, nothing owed to the producer of x): the same
+            # kernel without input transform, mask and sums - BatchNorm backward apply, dgrad and wgrad in one pass
+            coef, _, dg, db = Nm.backward(dout, y, None, mean, invstd, scale, shift, gamma, count, False, False, group,
+                                          ctx.beta, cache.stats_buffer(K, dout.device), coef_only=True)
+            r = C.bottleneck_tail_bwd(dout.view(-1, K), y.view(-1, K), coef, x.view(-1, Cin), None,
+                                      cache.transposed(weight, dout.dtype), C.grad_sink(weight))
+            if r is None:
+                raise RuntimeError("conv_bn_act: the fused shortcut backward refused a shape its caller checked")
+            C.notify_grad_ready(weight)
+            if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
+                dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
+            return (r[0].view(x.shape), None, dg, db, None, None, None, None, None, None, None, None, None, None, None)
         elif train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)

@@ -311,6 +311,53 @@ def test_bottleneck_tail_backward_fused(M, geom, dtype):
                                  x2[:, :64].contiguous(), (scale, shift), wt, dw) is None
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [64 * 700 + 11, 777])
+def test_bottleneck_tail_backward_plain_input(M, dtype):
+    """The same kernel on a shortcut branch (1x1 conv + BatchNorm of an activation): no input transform, no mask,
+    no sums."""
+    torch.manual_seed(14)
+    Ci, Co = 64, 256
+    dz = torch.randn(M, Co, device=DEV).to(dtype)
+    y3 = torch.randn(M, Co, device=DEV).to(dtype)
+    coef = torch.randn(5, Co, device=DEV) * torch.tensor([1.0, 0.1, 0.05, 1, 1], device=DEV).view(5, 1)
+    x = torch.randn(M, Ci, device=DEV).to(dtype)               # (negative values too: nothing may be masked)
+    w = (torch.randn(Co, 1, 1, Ci, device=DEV) / Ci ** 0.5).to(dtype)
+    base = torch.randn(Co, 1, 1, Ci, device=DEV)
+    dw = base.clone()
+    r = C.bottleneck_tail_bwd(dz, y3, coef, x, None, C.krsc_to_crsk(w, dtype), dw)
+    assert r is not None
+    dx, sums, dy = r
+    assert sums is None and dy is None
+    dy3 = (coef[0] * dz.float() + coef[1] * y3.float() + coef[2]).to(dtype)
+    assert rel_err(dx, dy3.float() @ w.view(Co, Ci).float()) < TOL[dtype]
+    assert rel_err((dw - base).view(Co, Ci), dy3.float().t() @ x.float()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_shortcut_conv_bn_backward_fused_matches_separate_kernels(dtype, monkeypatch):
+    """conv_bn_act of a 64 -> 256 shortcut (no activation): the one-pass backward against the separate kernels."""
+    torch.manual_seed(15)
+    x0 = torch.randn(6, 20, 20, 64, device=DEV).to(dtype)
+    conv = pnn.Conv2d(64, 256, 1, 1, 0, bias=False).to(DEV)
+    bn = pnn.BatchNorm2d(256).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    g = torch.randn(6, 20, 20, 256, device=DEV).to(dtype)
+    res = []
+    for level in (3, 0):
+        monkeypatch.setattr(fused, "_FUSE_TAIL_BWD", level)
+        for p in (conv.weight, bn.weight, bn.bias):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = pnn.ConvBnAct.run(conv, bn, x, relu=False)
+        out.backward(g)
+        res.append((x.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a_, b_ in zip(*res):
+        assert rel_err(a_, b_) < (2e-3 if dtype == torch.float16 else 1.5e-2)
+
+
 def test_batched_weight_transpose_refresh():
     """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
     torch.manual_seed(41)
