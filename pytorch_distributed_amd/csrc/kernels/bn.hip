@@ -290,19 +290,27 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict_
 // Every thread keeps one 16-byte channel vector for the whole grid-stride loop
 // (the stride is a multiple of the vectors per row), so scale/shift live in registers.
 // CAP (compile time): the activation is a ReLU clipped at `cap` (ReLU6); the plain instantiations are unchanged.
-template <typename T, bool CAP = false, int VB = 16>
+// RA (compile time): `res` is the output of a convolution whose own BatchNorm (no activation) has not been applied:
+// res * res_scale + res_shift is added - the shortcut branch of a residual block, normalised here instead of in a
+// pass of its own.
+template <typename T, bool CAP = false, int VB = 16, bool RA = false>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out,
                 const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
-                int relu, unsigned char* __restrict__ mask_out, int stream_out, float cap = 0.f) {
+                int relu, unsigned char* __restrict__ mask_out, int stream_out, float cap = 0.f,
+                const float* __restrict__ res_scale = nullptr, const float* __restrict__ res_shift = nullptr) {
   constexpr int EPC = VB / sizeof(T);
   const int vpr = C / EPC;
   const long long stride = (long long)gridDim.x * blockDim.x;  // host guarantees stride % vpr == 0
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int c0 = (int)(i % vpr) * EPC;
-  float sc[EPC], sf[EPC];
+  float sc[EPC], sf[EPC], rs[RA ? EPC : 1];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sf[e] = shift[c0 + e]; }
+  if (RA) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { rs[e] = res_scale[c0 + e]; sf[e] += res_shift[c0 + e]; }
+  }
   for (; i < nvec; i += stride) {
     VecB<T, VB> v = ldv_stream<T, VB>(y + i * EPC);
     VecB<T, VB> rv;
@@ -311,7 +319,8 @@ bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res, T* __restric
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float f = ElemTraits<T>::to_f32(v.v[e]) * sc[e] + sf[e];
-      if (res) f += ElemTraits<T>::to_f32(rv.v[e]);
+      if (RA) f += ElemTraits<T>::to_f32(rv.v[e]) * rs[e];
+      else if (res) f += ElemTraits<T>::to_f32(rv.v[e]);
       if (relu) f = fmaxf(f, 0.f);
       if (CAP) f = fminf(f, cap);
       o.v[e] = ElemTraits<T>::from_f32(f);
@@ -738,6 +747,25 @@ static int bn_apply_impl(int dtype, const void* y, const void* res, void* out, c
 PDA_EXPORT int pda_bn_apply(int dtype, const void* y, const void* res, void* out, const float* scale,
                             const float* shift, long long M, int C, int relu, hipStream_t st) {
   return bn_apply_impl(dtype, y, res, out, scale, shift, M, C, relu, nullptr, st);
+}
+
+// out = relu(y * scale + shift + res * res_scale + res_shift): both branches of a residual block's end normalised in
+// one pass (res = the shortcut convolution's raw output); mask_out as in pda_bn_apply_mask, or null.
+PDA_EXPORT int pda_bn_apply_res_affine(int dtype, const void* y, const void* res, void* out, const float* scale,
+                                       const float* shift, const float* res_scale, const float* res_shift, long long M,
+                                       int C, int relu, unsigned char* mask_out, hipStream_t st) {
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  const int vb = bn_vec_bytes(C, es);
+  if (!res || !res_scale || !res_shift) return -11;
+  if (vb == 0 || (M * C * es) % vb != 0 || (mask_out != nullptr && vb != 16)) return -1;
+  const long long nvec = M * C / (vb / es);
+  if (nvec == 0) return 0;
+  const int vpr = C / (vb / es);
+  PDA_DISPATCH_TVB(dtype, vb, hipLaunchKernelGGL((bn_apply_kernel<T, false, VB, true>), dim3(ew_blocks_chan(nvec, vpr)),
+                                                 dim3(256), 0, st, (const T*)y, (const T*)res, (T*)out, scale, shift, nvec,
+                                                 C, relu, mask_out, (int)(nvec * vb >= pda_stream_min_bytes()), 0.f,
+                                                 res_scale, res_shift));
+  return pda_check_launch();
 }
 
 // out = min(relu(y * scale + shift + res), cap): BatchNorm + clipped ReLU (ReLU6) in one pass.

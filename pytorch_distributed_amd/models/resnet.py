@@ -23,7 +23,7 @@ import torch.nn as tnn
 
 from .. import nn as pnn
 from .. import ops
-from ..ops.fused import BNBackwardLink
+from ..ops.fused import BNBackwardLink, ShortcutLink
 
 
 # bit i = the i-th inner hand-off of a block may skip its normalisation pass.  Default: only the hand-off into a
@@ -93,10 +93,13 @@ class BasicBlock(tnn.Module):
         out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True,
                                           mask_dx=self.premask_in, in_link=in_link,
                                           dout_premasked=l1[0] is not None, out_link=l1[0])
+        sl = None
         if self.downsample is not None:
-            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
+            # the shortcut's BatchNorm is applied by the block's last op, in the pass that adds it
+            sl = ShortcutLink()
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False, res_out=sl)
         return pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, residual=identity, in_link=l1[0],
-                                 dout_premasked=pm, out_link=lo)
+                                 dout_premasked=pm, out_link=lo, res_in=sl)
 
 
 class Bottleneck(tnn.Module):
@@ -128,10 +131,13 @@ class Bottleneck(tnn.Module):
                                           dout_premasked=l1 is not None, out_link=l1)
         out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, in_link=l1,
                                 dout_premasked=l2 is not None, out_link=l2)
+        sl = None
         if self.downsample is not None:
-            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False)
+            # the shortcut's BatchNorm is applied by the block's last op, in the pass that adds it
+            sl = ShortcutLink()
+            identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False, res_out=sl)
         return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity, in_link=l2,
-                                 dout_premasked=pm, out_link=lo)
+                                 dout_premasked=pm, out_link=lo, res_in=sl)
 
 
 class ResNet(tnn.Module):

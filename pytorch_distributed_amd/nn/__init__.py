@@ -137,10 +137,17 @@ class ConvBnAct(tnn.Module):
     @staticmethod
     def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
             residual: Optional[torch.Tensor] = None, passthrough: bool = False, mask_dx: bool = False,
-            dout_premasked: bool = False, in_link=None, out_link=None):
-        """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link``: see
+            dout_premasked: bool = False, in_link=None, out_link=None, res_in=None, res_out=None):
+        """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link`` / ``res_in`` / ``res_out``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
         pointwise = conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+        fused_path = (conv.bias is None and conv.groups == 1 and conv.out_channels % 8 == 0
+                      and bool(_conv.igemm_tiles(conv.in_channels, x.dtype))
+                      and (pointwise or bool(_conv.igemm_tiles(conv.out_channels, x.dtype))))
+        if res_in is not None and res_in.affine is not None and not fused_path:
+            # only the fused op adds a shortcut that its producer left un-normalised
+            from ..ops.fused import materialize_shortcut
+            residual, res_in = materialize_shortcut(residual, res_in), None
         plain = not (passthrough or mask_dx or dout_premasked or in_link is not None or out_link is not None)
         if (conv.bias is not None and plain and x.is_cuda and bn.training and bn.track_running_stats
                 and bn.momentum is not None and conv.groups == 1 and conv.out_channels % 8 == 0
@@ -171,7 +178,8 @@ class ConvBnAct(tnn.Module):
             o = bn(conv(x), residual, relu)
             return (o, x) if passthrough else o
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
-                               bn.state(), conv._cache, passthrough, mask_dx, dout_premasked, in_link, out_link)
+                               bn.state(), conv._cache, passthrough, mask_dx, dout_premasked, in_link, out_link,
+                               res_in, res_out)
 
 
 class ReLU(tnn.Module):

@@ -77,6 +77,7 @@ _DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
 _FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "3"))   # 1: 64->256 tails, 2: + 128->512 tails, 3: + 64->256 shortcut
 # Backward of the stem: BatchNorm backward apply + weight gradient in one pass (csrc/kernels/stem_bwd.hip).
 _FUSE_STEM_BWD = os.environ.get("PDA_FUSE_STEM_BWD", "1") == "1"
+_DEFER_SHORTCUT = os.environ.get("PDA_DEFER_SHORTCUT", "1") == "1"
 
 
 class BNBackwardLink:
@@ -111,12 +112,48 @@ class BNBackwardLink:
         self.deferred = False
 
 
+class ShortcutLink:
+    """Hand-off between the conv + BatchNorm of a residual block's shortcut (the producer, called with
+    ``res_out=link``) and the block's last fused op, which adds the shortcut as its ``residual`` (called with
+    ``res_in=link``).  In training the producer then skips its normalisation pass: it returns its raw conv output
+    and leaves the BatchNorm's ``(scale, shift)`` here, and the consumer's apply kernel adds
+    ``residual * scale + shift`` - one write and one read of the block-wide tensor less.  Towards autograd the raw
+    tensor stands for the normalised one (the gradient of an affine map's output is what the producer's BatchNorm
+    backward expects), so ``residual`` must have no other use.  ``affine`` stays ``None`` whenever the producer did
+    normalise (evaluation, CPU, unfused layers)."""
+
+    __slots__ = ("affine",)
+
+    def __init__(self):
+        self.affine = None
+
+
+class _AffineFn(torch.autograd.Function):
+    """``y * scale + shift`` of a shortcut whose producer left the normalisation to a consumer that cannot do it."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift):
+        return Nm.apply(y.contiguous(), scale, shift, None, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+def materialize_shortcut(residual, res_in):
+    """``residual`` itself, or its normalised form if ``res_in`` says the producer skipped that pass."""
+    if res_in is None or res_in.affine is None:
+        return residual
+    return _AffineFn.apply(residual, *res_in.affine)
+
+
 class _ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, stride, pad, relu: bool, st: Nm.BNState,
                 cache: C.WeightCache, passthrough: bool = False, mask_dx: bool = False,
                 dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
-                out_link: Optional[BNBackwardLink] = None):
+                out_link: Optional[BNBackwardLink] = None, res_in: Optional[ShortcutLink] = None,
+                res_out: Optional[ShortcutLink] = None):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -162,7 +199,13 @@ class _ConvBnActFn(torch.autograd.Function):
             if gamma is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
                 mean, invstd = Nm.eval_moments(st)   # frozen statistics, trainable affine
             count = float(y.numel() // K)
-        if defer:
+        res_aff = res_in.affine if (res_in is not None and residual is not None) else None
+        if (res_out is not None and _DEFER_SHORTCUT and train_stats and not relu and residual is None and not passthrough
+                and out_link is None and not defer):
+            # a shortcut branch: the block's last op adds y * scale + shift itself (see ShortcutLink)
+            out = y
+            res_out.affine = (scale, shift)
+        elif defer:
             # the consumer normalises on load; autograd still sees this tensor as "the activation"
             out = y
             out_link.deferred = True
@@ -174,9 +217,9 @@ class _ConvBnActFn(torch.autograd.Function):
         elif (out_link is not None and ctx.premasked and residual is not None and _MASK_BITS
               and K % (16 // y.element_size()) == 0):
             # the consumer masks this op's gradient: hand it the sign bits, 1/16 of the activation's bytes
-            out, out_link.maskbits = Nm.apply(y, scale, shift, residual, relu, want_mask=True)
+            out, out_link.maskbits = Nm.apply(y, scale, shift, residual, relu, want_mask=True, res_affine=res_aff)
         else:
-            out = Nm.apply(y, scale, shift, residual, relu)
+            out = Nm.apply(y, scale, shift, residual, relu, res_affine=res_aff)
         ctx.cfg = (stride, pad, relu, residual is not None, count, st.group, cache, train_stats)
         ctx.beta = beta
         ctx.mask_dx = mask_dx
@@ -240,7 +283,7 @@ class _ConvBnActFn(torch.autograd.Function):
                 C.notify_grad_ready(weight)
                 if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
                     dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-                return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None)
+                return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None)
             dy = r[2].view(y.shape)
         elif (_FUSE_TAIL_BWD >= 3 and train_stats and geom_small and not relu and not has_res and not ctx.premasked
               and ctx.out_link is None and link is None and ctx.in_aff is None and not ctx.mask_dx and dalias is None
@@ -258,7 +301,7 @@ class _ConvBnActFn(torch.autograd.Function):
             C.notify_grad_ready(weight)
             if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
                 dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-            return (r[0].view(x.shape), None, dg, db, None, None, None, None, None, None, None, None, None, None, None)
+            return (r[0].view(x.shape), None, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None)
         elif train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)
@@ -355,13 +398,14 @@ class _ConvBnActFn(torch.autograd.Function):
                     dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNState,
                 cache: Optional[C.WeightCache] = None, passthrough: bool = False, mask_dx: bool = False,
                 dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
-                out_link: Optional[BNBackwardLink] = None):
+                out_link: Optional[BNBackwardLink] = None, res_in: Optional[ShortcutLink] = None,
+                res_out: Optional[ShortcutLink] = None):
     """NHWC fused conv + BatchNorm (+residual) (+ReLU).
 
     ``relu``: ``False``, ``True``, or a positive number ``c`` for a ReLU clipped at ``c`` (ReLU6: ``relu=6.0``),
@@ -383,7 +427,13 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNSt
     ``out_link`` (with ``dout_premasked=True``) / ``in_link``: a :class:`BNBackwardLink` shared by this op
     and the single consumer of its output, through which the consumer's dgrad epilogue also delivers the
     reductions of this op's BatchNorm backward.  A consumer given ``in_link`` always applies the
-    producer's ReLU mask, so the pair stays correct when the sums cannot be produced."""
+    producer's ReLU mask, so the pair stays correct when the sums cannot be produced.
+
+    ``res_out`` / ``res_in``: a :class:`ShortcutLink` shared by a shortcut branch's op (no activation) and the op
+    that takes its output as ``residual``."""
+    if res_in is not None and res_in.affine is not None and (not x.is_cuda or Nm.relu_cap(relu) is not None):
+        residual = materialize_shortcut(residual, res_in)
+        res_in = None
     if Nm.relu_cap(relu) is not None and (dout_premasked or out_link is not None):
         raise ValueError("conv_bn_act: a clipped ReLU cannot hand its mask to the consumer (dout_premasked / out_link)")
     if not x.is_cuda:
@@ -392,12 +442,13 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNSt
         o = Nm.batch_norm_act_ref(y, gamma, beta, residual, relu, st)
         return (o, x) if passthrough else o
     if not torch.is_grad_enabled() and not st.training and st.running_mean is not None and _FOLD_EVAL_BN:
-        o = _conv_folded_bn(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
-                            cache or C.WeightCache())
+        o = _conv_folded_bn(x, weight, gamma, beta, materialize_shortcut(residual, res_in), tuple(stride), tuple(pad),
+                            relu, st, cache or C.WeightCache())
         if o is not None:
             return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
-                              cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link)
+                              cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link,
+                              res_in, res_out)
 
 
 class _MaterializeFn(torch.autograd.Function):

@@ -186,15 +186,28 @@ def relu_mask(out: torch.Tensor, relu) -> torch.Tensor:
     return (out > 0) if cap is None else ((out > 0) & (out < cap))
 
 
-def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu, want_mask: bool = False):
+def apply(y: torch.Tensor, scale, shift, res: Optional[torch.Tensor], relu, want_mask: bool = False,
+          res_affine: Optional[tuple] = None):
     """``relu(y * scale + shift + res)``.  ``want_mask``: also return the sign bits of the result, one byte per
     16-byte vector (bit e = element e is positive): what the ReLU backward needs of this tensor, at 1/16 of its
-    size (``conv.dgrad_gpu(mask=..., mask_bits=True)``)."""
+    size (``conv.dgrad_gpu(mask=..., mask_bits=True)``).
+
+    ``res_affine = (scale_r, shift_r)`` (fp32 ``[C]``): ``res`` is the raw output of the shortcut convolution and
+    ``res * scale_r + shift_r`` is added - its BatchNorm applied here instead of in a pass of its own."""
     l = _lib.lib()
     C = y.shape[-1]
     M = y.numel() // C
     out = torch.empty_like(y)
     cap = relu_cap(relu)
+    if res_affine is not None:
+        if cap is not None or res is None:
+            raise ValueError("norm.apply: res_affine needs a residual and a plain (or no) ReLU")
+        bits = (torch.empty(y.numel() * y.element_size() // 16, device=y.device, dtype=torch.uint8) if want_mask
+                else None)
+        _lib.check(l.pda_bn_apply_res_affine(_lib.dt(y), y.data_ptr(), res.data_ptr(), out.data_ptr(), scale.data_ptr(),
+                                             shift.data_ptr(), res_affine[0].data_ptr(), res_affine[1].data_ptr(), M, C,
+                                             int(relu), _lib.ptr(bits), _lib.stream()), "pda_bn_apply_res_affine")
+        return (out, bits) if want_mask else out
     if cap is not None:
         if want_mask:
             raise ValueError("norm.apply: sign-bit masks describe a plain ReLU, not a clipped one")

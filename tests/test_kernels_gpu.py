@@ -358,6 +358,61 @@ def test_shortcut_conv_bn_backward_fused_matches_separate_kernels(dtype, monkeyp
         assert rel_err(a_, b_) < (2e-3 if dtype == torch.float16 else 1.5e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C_", [256, 24])
+def test_bn_apply_with_shortcut_affine(dtype, C_):
+    """relu(y*scale + shift + res*scale_r + shift_r): the shortcut's BatchNorm applied in the block-end pass, with and
+    without the sign-bit mask."""
+    torch.manual_seed(16)
+    y = torch.randn(3, 9, 7, C_, device=DEV).to(dtype)
+    res = torch.randn(3, 9, 7, C_, device=DEV).to(dtype)
+    sc, sf, rs, rf = (torch.randn(C_, device=DEV) for _ in range(4))
+    ref = torch.relu(y.float() * sc + sf + res.float() * rs + rf)
+    out = Nm.apply(y, sc, sf, res, True, res_affine=(rs, rf))
+    assert rel_err(out, ref) < TOL[dtype]
+    out_lin = Nm.apply(y, sc, sf, res, False, res_affine=(rs, rf))
+    assert rel_err(out_lin, y.float() * sc + sf + res.float() * rs + rf) < TOL[dtype]
+    if C_ % (16 // y.element_size()) == 0:
+        out2, bits = Nm.apply(y, sc, sf, res, True, want_mask=True, res_affine=(rs, rf))
+        assert torch.equal(out2, out)
+        assert torch.equal(C.unpack_mask_bits(bits, out2) > 0, out2 > 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bottleneck_with_deferred_shortcut_matches_applied(dtype, stride, monkeypatch):
+    """A bottleneck with a shortcut conv: the shortcut's BatchNorm folded into the block-end pass against the
+    separately normalised shortcut - same output, input gradient and parameter gradients."""
+    from pytorch_distributed_amd.models.resnet import Bottleneck
+    import torch.nn as tnn
+    torch.manual_seed(17)
+    ds = tnn.Sequential(pnn.Conv2d(64, 256, 1, stride, 0, bias=False), pnn.BatchNorm2d(256))
+    blk = Bottleneck(64, 64, stride, ds).to(DEV)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, pnn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x0 = torch.randn(4, 16, 16, 64, device=DEV).to(dtype)
+    g = None
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(fused, "_DEFER_SHORTCUT", on)
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = blk(x)
+        if g is None:
+            g = torch.randn_like(out)
+        out.backward(g)
+        res.append([out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    # fp32: the same arithmetic.  16-bit: the separately normalised shortcut is rounded once more before the add, so
+    # outputs within an ulp of zero land on the other side of the ReLU and their gradient paths differ
+    assert rel_err(res[0][0], res[1][0]) < {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1e-2}[dtype]
+    tol = {torch.float32: 1e-5, torch.float16: 0.12, torch.bfloat16: 0.3}[dtype]
+    for a_, b_ in zip(res[0][1:], res[1][1:]):
+        assert rel_err(a_, b_) < tol
+
+
 def test_batched_weight_transpose_refresh():
     """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
     torch.manual_seed(41)
