@@ -32,6 +32,8 @@ struct ConvArgs {
   const void* mask; // optional [M][Co]: output elements whose mask value is <= 0 are written as 0 (after res);
                     // with mask_bits: one byte per 16-byte vector of that tensor, bit e = element e is positive
   int mask_bits;
+  int res_s2;       // dgrad with the fused epilogue: `res` is the compact [N][ceil(Ho/2)][ceil(Wo/2)][Co] gradient of a
+                    // stride-2 1x1 shortcut - it is added at the pixels with even row and column, nothing elsewhere
   int stream_out;   // the output is far larger than the caches: non-temporal stores (host-decided by its size)
   // BatchNorm backward of the layer that produced this conv's input, folded into a dgrad epilogue:
   // bnc = that layer's pre-normalisation tensor [M][Co].  With bn_scale/bn_shift the layer's ReLU mask
@@ -933,9 +935,25 @@ igemm_kernel(ConvArgs a) {
         if (!vec_offset(m0e, k, eo[k])) eo[k] = -1;
     }
     Vec16<T> rv[KE], mv[KE];
+    unsigned rskip = 0u;   // bit k: the k-th vector gets no residual (odd row or column of a stride-2 shortcut)
     if (Rz != nullptr) {
+      if (EX && a.res_s2) {
+        const int H2 = (a.Ho + 1) >> 1, W2 = (a.Wo + 1) >> 1;
 #pragma unroll
-      for (int k = 0; k < KE; ++k) rv[k] = load16_stream(Rz + (eo[k] < 0 ? 0 : eo[k]));
+        for (int k = 0; k < KE; ++k) {
+          const int v = t + NT * k;
+          const int m = eo[k] < 0 ? 0 : m0e + v / VPR;
+          const int hq = m / a.Wo, pw = m - hq * a.Wo;
+          const int pn = hq / a.Ho, ph = hq - pn * a.Ho;
+          const bool even = eo[k] >= 0 && ((ph | pw) & 1) == 0;
+          if (!even) rskip |= 1u << k;
+          const long long ro = (((long long)pn * H2 + (ph >> 1)) * W2 + (pw >> 1)) * a.Co + n0 + (v % VPR) * EPC;
+          rv[k] = load16_stream(Rz + (even ? ro : 0));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KE; ++k) rv[k] = load16_stream(Rz + (eo[k] < 0 ? 0 : eo[k]));
+      }
     }
     if (Mk != nullptr) {
       if (a.mask_bits) {
@@ -1006,7 +1024,7 @@ igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + bs[e]);
         }
-        if (Rz != nullptr) {
+        if (Rz != nullptr && !((rskip >> k) & 1u)) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e)
             val.v[e] = ElemTraits<T>::from_f32(ElemTraits<T>::to_f32(val.v[e]) + ElemTraits<T>::to_f32(rv[EX ? k : 0].v[e]));
@@ -1705,7 +1723,10 @@ static int conv_igemm_impl(int dtype, int dgrad, const void* x, const void* w, v
     a.csplit = ((Ci + ksplit - 1) / ksplit + 127) / 128 * 128;
     a.ksplit = (Ci + a.csplit - 1) / a.csplit;
   }
-  a.mask_bits = mask != nullptr ? mask_bits : 0;
+  a.mask_bits = mask != nullptr ? (mask_bits & 1) : 0;
+  a.res_s2 = (mask_bits >> 1) & 1;
+  if (a.res_s2 && (res == nullptr || dgrad == 0 || stride_h != 1 || stride_w != 1 || dtype == PDA_F32 || Co % 8 != 0))
+    return -14;   // the compact residual exists in the vector epilogue of the stride-1 dgrad only
   a.stream_out = (long long)N * Ho * Wo * Co * (dtype == PDA_F32 ? 4 : 2) >= pda_stream_min_bytes();
   if ((((uintptr_t)in_scale | (uintptr_t)in_shift) & 15) != 0) return -5;
   a.stat_slots = stat_slots;
@@ -1796,6 +1817,20 @@ PDA_EXPORT int pda_conv_igemm_maskbits(int dtype, int dgrad, const void* x, cons
   return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
                          sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
                          nullptr, stream, 1);
+}
+
+// pda_conv_igemm with flags: bit 0 = `mask` is given as sign bits (pda_conv_igemm_maskbits), bit 1 = `res` is the
+// compact gradient [N][ceil(Ho/2)][ceil(Wo/2)][Co] of a stride-2 1x1 shortcut (stride-1 dgrad only): added at the
+// pixels with even row and column.
+PDA_EXPORT int pda_conv_igemm_flags(int dtype, int dgrad, const void* x, const void* w, void* y, const void* res,
+                                    const void* mask, const void* bnc, const float* bn_scale, const float* bn_shift,
+                                    float* psum, float* psq, int N, int Hi, int Wi, int Ci, long long sn,
+                                    long long sh, long long sw, int Ho, int Wo, int Co, int R, int S, int stride_h,
+                                    int stride_w, int pad_h, int pad_w, int relu, int cfg, int stat_slots, int flags,
+                                    hipStream_t stream) {
+  return conv_igemm_impl(dtype, dgrad, x, w, y, res, mask, bnc, bn_scale, bn_shift, psum, psq, N, Hi, Wi, Ci, sn, sh,
+                         sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h, pad_w, relu, cfg, stat_slots, nullptr,
+                         nullptr, stream, flags);
 }
 
 // acc[M][N] (fp32, zero or holding a value to add to) += x[M][K] * w[N][K]^T with the reduction split `ksplit` ways

@@ -126,15 +126,15 @@ class Bottleneck(tnn.Module):
 
     def forward(self, x):
         in_link, (l1, l2), lo, pm = _links(self, 2)
+        sl = ShortcutLink() if self.downsample is not None else None
         out, identity = pnn.ConvBnAct.run(self.conv1, self.bn1, x, relu=True, passthrough=True,
                                           mask_dx=self.premask_in, in_link=in_link,
-                                          dout_premasked=l1 is not None, out_link=l1)
+                                          dout_premasked=l1 is not None, out_link=l1, alias_link=sl)
         out = pnn.ConvBnAct.run(self.conv2, self.bn2, out, relu=True, in_link=l1,
                                 dout_premasked=l2 is not None, out_link=l2)
-        sl = None
         if self.downsample is not None:
-            # the shortcut's BatchNorm is applied by the block's last op, in the pass that adds it
-            sl = ShortcutLink()
+            # the shortcut's BatchNorm is applied by the block's last op, in the pass that adds it; a strided
+            # shortcut's input gradient travels back to conv1's dgrad epilogue in compact form
             identity = pnn.ConvBnAct.run(self.downsample[0], self.downsample[1], identity, relu=False, res_out=sl)
         return pnn.ConvBnAct.run(self.conv3, self.bn3, out, relu=True, residual=identity, in_link=l2,
                                  dout_premasked=pm, out_link=lo, res_in=sl)

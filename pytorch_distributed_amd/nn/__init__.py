@@ -137,8 +137,9 @@ class ConvBnAct(tnn.Module):
     @staticmethod
     def run(conv: Conv2d, bn: BatchNorm2d, x: torch.Tensor, relu: bool = True,
             residual: Optional[torch.Tensor] = None, passthrough: bool = False, mask_dx: bool = False,
-            dout_premasked: bool = False, in_link=None, out_link=None, res_in=None, res_out=None):
-        """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link`` / ``res_in`` / ``res_out``: see
+            dout_premasked: bool = False, in_link=None, out_link=None, res_in=None, res_out=None,
+            alias_link=None):
+        """``mask_dx`` / ``dout_premasked`` / ``in_link`` / ``out_link`` / ``res_in`` / ``res_out`` / ``alias_link``: see
         :func:`pytorch_distributed_amd.ops.conv_bn_act`."""
         pointwise = conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
         fused_path = (conv.bias is None and conv.groups == 1 and conv.out_channels % 8 == 0
@@ -179,7 +180,7 @@ class ConvBnAct(tnn.Module):
             return (o, x) if passthrough else o
         return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, residual, conv.stride, conv.padding, relu,
                                bn.state(), conv._cache, passthrough, mask_dx, dout_premasked, in_link, out_link,
-                               res_in, res_out)
+                               res_in, res_out, alias_link)
 
 
 class ReLU(tnn.Module):

@@ -216,10 +216,12 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
               res: Optional[torch.Tensor] = None, cfg: int = 0, mask: Optional[torch.Tensor] = None,
               bn_input: Optional[torch.Tensor] = None, bn_scale: Optional[torch.Tensor] = None,
               bn_shift: Optional[torch.Tensor] = None, bn_sums: bool = False, mask_bits: bool = False,
-              sums_buf: Optional[torch.Tensor] = None):
+              sums_buf: Optional[torch.Tensor] = None, res_s2: bool = False):
     """dx[N,Hi,Wi,C] from dy[N,Ho,Wo,K]; w_crsk is the [C,R,S,K] transposed weight.
 
-    ``res`` ([N,Hi,Wi,C]) is added in the epilogue; ``mask`` ([N,Hi,Wi,C], the forward input when that
+    ``res`` ([N,Hi,Wi,C]) is added in the epilogue; with ``res_s2`` it is the compact
+    ``[N, ceil(Hi/2), ceil(Wi/2), C]`` input gradient of a stride-2 1x1 shortcut conv over the same input, added at
+    the pixels with even row and column (stride-1 convs in a 16-bit type; ``None`` is returned otherwise); ``mask`` ([N,Hi,Wi,C], the forward input when that
     input was a ReLU output) zeroes dx wherever ``mask <= 0`` - the ReLU backward of the producer, applied
     where the gradient is written instead of by a later pass over it.  With ``mask_bits`` the mask is the
     uint8 sign-bit tensor of that input (``norm.apply(want_mask=True)``: one byte per 16-byte vector).
@@ -238,15 +240,22 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     if cfg == 0 and backends.benchmark:
         extras = res is not None or mask is not None or bn_input is not None
         cfg = _tuned_cfg("dgrad", (dy.dtype, N, Ho, Wo, K, C, R, S, Hi, Wi, tuple(stride), tuple(pad), res is not None,
-                                   mask is not None, bn_input is not None, bn_scale is not None, bn_sums, mask_bits),
+                                   mask is not None, bn_input is not None, bn_scale is not None, bn_sums, mask_bits,
+                                   res_s2),
                          _DGRAD_EX_CFGS if extras else _FPROP_CFGS,
                          lambda c: dgrad_gpu(dy, w_crsk, in_hw, stride, pad, res, c or 1 << 30, mask, bn_input, bn_scale,
-                                             bn_shift, bn_sums, mask_bits))
+                                             bn_shift, bn_sums, mask_bits, None, res_s2))
     cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
-    for name, t in (("res", res), ("mask", None if mask_bits else mask), ("bn_input", bn_input)):
+    for name, t in (("res", None if res_s2 else res), ("mask", None if mask_bits else mask), ("bn_input", bn_input)):
         if t is not None and (t.shape != dx.shape or t.dtype != dx.dtype or not t.is_contiguous()):
             raise ValueError(f"dgrad_gpu: {name} must be a contiguous {tuple(dx.shape)} {dx.dtype} tensor")
+    if res_s2:
+        if res is None or tuple(res.shape) != (N, (Hi + 1) // 2, (Wi + 1) // 2, C) or res.dtype != dx.dtype \
+                or not res.is_contiguous():
+            raise ValueError("dgrad_gpu: res_s2 wants a contiguous [N, ceil(Hi/2), ceil(Wi/2), C] residual")
+        if tuple(stride) != (1, 1) or dx.element_size() != 2 or C % 8:
+            return None
     if mask_bits and mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous()
                                            or mask.numel() != dx.numel() * dx.element_size() // 16):
         raise ValueError("dgrad_gpu: mask_bits wants one contiguous uint8 per 16 bytes of dx")
@@ -261,12 +270,12 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
             sums, slots = sums_buf, sums_buf.shape[1]
         else:
             sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
-    entry = l.pda_conv_igemm_maskbits if (mask_bits and mask is not None) else l.pda_conv_igemm
-    rc = entry(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
-                          _lib.ptr(mask), _lib.ptr(bn_input), _lib.ptr(bn_scale), _lib.ptr(bn_shift),
-                          sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
-                          Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg, slots,
-                          _lib.stream())
+    flags = (1 if (mask_bits and mask is not None) else 0) | (2 if res_s2 else 0)
+    rc = l.pda_conv_igemm_flags(_lib.dt(dy), 1, dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(), _lib.ptr(res),
+                                _lib.ptr(mask), _lib.ptr(bn_input), _lib.ptr(bn_scale), _lib.ptr(bn_shift),
+                                sums[0].data_ptr() if bn_sums else 0, sums[1].data_ptr() if bn_sums else 0, N, Ho, Wo, K,
+                                Ho * Wo * K, Wo * K, K, Hi, Wi, C, R, S, stride[0], stride[1], pad[0], pad[1], 0, cfg,
+                                slots, flags, _lib.stream())
     if rc == -8:
         # 16-bit dX whose channel count is not a multiple of 8: the epilogue extras only exist in the
         # vector write-out, so run the plain kernel and apply them with tensor ops (no sums: the caller's
@@ -274,7 +283,9 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
         dx = dgrad_gpu(dy, w_crsk, in_hw, stride, pad, cfg=cfg)
         if dx is None:
             return None
-        if res is not None:
+        if res is not None and res_s2:
+            dx[:, ::2, ::2] += res
+        elif res is not None:
             dx += res
         if mask is not None:
             dx *= unpack_mask_bits(mask, dx) if mask_bits else (mask > 0).to(dx.dtype)

@@ -78,6 +78,7 @@ _FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "3"))   # 1: 64->256 ta
 # Backward of the stem: BatchNorm backward apply + weight gradient in one pass (csrc/kernels/stem_bwd.hip).
 _FUSE_STEM_BWD = os.environ.get("PDA_FUSE_STEM_BWD", "1") == "1"
 _DEFER_SHORTCUT = os.environ.get("PDA_DEFER_SHORTCUT", "1") == "1"
+_COMPACT_SHORTCUT_GRAD = os.environ.get("PDA_COMPACT_SHORTCUT_GRAD", "1") == "1"
 
 
 class BNBackwardLink:
@@ -120,12 +121,21 @@ class ShortcutLink:
     ``residual * scale + shift`` - one write and one read of the block-wide tensor less.  Towards autograd the raw
     tensor stands for the normalised one (the gradient of an affine map's output is what the producer's BatchNorm
     backward expects), so ``residual`` must have no other use.  ``affine`` stays ``None`` whenever the producer did
-    normalise (evaluation, CPU, unfused layers)."""
+    normalise (evaluation, CPU, unfused layers).
 
-    __slots__ = ("affine",)
+    The same object carries the shortcut's input gradient the other way when the shortcut is a stride-2 1x1 conv and
+    the block's first op (called with ``alias_link=link``; it owns the skip branch through ``passthrough``) is a
+    stride-1 conv on the fused path: three quarters of that gradient are zeros, so the shortcut's backward computes
+    only the compact ``[N, ceil(H/2), ceil(W/2), C]`` part, leaves it in ``dx_compact`` and hands autograd a
+    zero-stride placeholder of the full shape; the first op's dgrad epilogue adds the compact tensor at the even
+    pixels instead of reading a full-size one (``conv.dgrad_gpu(res_s2=True)``)."""
+
+    __slots__ = ("affine", "compact_ok", "dx_compact")
 
     def __init__(self):
         self.affine = None
+        self.compact_ok = False
+        self.dx_compact = None
 
 
 class _AffineFn(torch.autograd.Function):
@@ -153,7 +163,7 @@ class _ConvBnActFn(torch.autograd.Function):
                 cache: C.WeightCache, passthrough: bool = False, mask_dx: bool = False,
                 dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
                 out_link: Optional[BNBackwardLink] = None, res_in: Optional[ShortcutLink] = None,
-                res_out: Optional[ShortcutLink] = None):
+                res_out: Optional[ShortcutLink] = None, alias_link: Optional[ShortcutLink] = None):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -225,6 +235,12 @@ class _ConvBnActFn(torch.autograd.Function):
         ctx.mask_dx = mask_dx
         ctx.in_aff = in_aff
         ctx.in_link = in_link
+        ctx.res_out = res_out
+        ctx.alias_link = alias_link if passthrough else None
+        if ctx.alias_link is not None:
+            alias_link.dx_compact = None
+            alias_link.compact_ok = (_COMPACT_SHORTCUT_GRAD and tuple(stride) == (1, 1) and x.element_size() == 2
+                                     and Cin % 8 == 0 and ctx.needs_input_grad[0])
         ctx.out_link = out_link if dout_premasked else None
         if ctx.out_link is not None:
             out_link.relu = relu
@@ -258,6 +274,11 @@ class _ConvBnActFn(torch.autograd.Function):
             presums_clear = presums is not None and presums is ctx.out_link.sums_buf
             ctx.out_link.y = None
         link = ctx.in_link
+        # the skip branch's gradient may have come the compact way (see ShortcutLink): `dalias` is a placeholder then
+        res_c = None
+        if ctx.alias_link is not None and ctx.alias_link.dx_compact is not None:
+            res_c, ctx.alias_link.dx_compact = ctx.alias_link.dx_compact, None
+            dalias = None
         tail_dx = None
         geom_small = (K, Cin, R, S) == (256, 64, 1, 1)
         if (_FUSE_TAIL_BWD and train_stats and ctx.premasked and presums is not None and ctx.in_aff is not None
@@ -283,7 +304,7 @@ class _ConvBnActFn(torch.autograd.Function):
                 C.notify_grad_ready(weight)
                 if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
                     dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-                return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None)
+                return (tail_dx, None, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None)
             dy = r[2].view(y.shape)
         elif (_FUSE_TAIL_BWD >= 3 and train_stats and geom_small and not relu and not has_res and not ctx.premasked
               and ctx.out_link is None and link is None and ctx.in_aff is None and not ctx.mask_dx and dalias is None
@@ -301,7 +322,7 @@ class _ConvBnActFn(torch.autograd.Function):
             C.notify_grad_ready(weight)
             if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
                 dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-            return (r[0].view(x.shape), None, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None)
+            return (r[0].view(x.shape), None, dg, db, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
         elif train_stats and (ctx.premasked or (ctx.out_link is not None and not relu)):
             # the consumer of `out` already zeroed the gradient where out <= 0: no mask to read, and the
             # residual branch's gradient IS dout; with presums it also took the reduction over (dout, y)
@@ -338,10 +359,23 @@ class _ConvBnActFn(torch.autograd.Function):
                 streams.mark(dy.device)
                 C.notify_grad_ready(weight)
                 wgrad_done = True
+        sl = ctx.res_out
         if tail_dx is not None:
             dx = tail_dx
+        elif (ctx.needs_input_grad[0] and sl is not None and sl.compact_ok and (R, S) == (1, 1) and tuple(stride) == (2, 2)
+              and tuple(pad) == (0, 0) and dalias is None and link is None and not ctx.mask_dx and dy.element_size() == 2
+              and K % 8 == 0 and Cin % 8 == 0):
+            # a stride-2 1x1 shortcut: only the even pixels of x have a gradient - a plain GEMM on the output grid;
+            # the op that owns x adds it from there (autograd gets a zero-stride stand-in of the full shape)
+            dxc = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (dy.shape[1], dy.shape[2]), (1, 1), (0, 0))
+            if dxc is None:
+                raise RuntimeError("conv_bn_act: no pointwise dgrad kernel for the compact shortcut gradient")
+            sl.dx_compact = dxc
+            dx = dxc.as_strided(x.shape, (0, 0, 0, 0))
         elif ctx.needs_input_grad[0]:
-            if dalias is not None:
+            if res_c is not None:
+                dalias = None
+            elif dalias is not None:
                 dalias = dalias.contiguous()
             # what this op does on behalf of the op that produced x (see BNBackwardLink)
             link = ctx.in_link
@@ -357,9 +391,19 @@ class _ConvBnActFn(torch.autograd.Function):
                     and link.maskbits.numel() * 16 == x.numel() * x.element_size()):
                 mk, mkbits = link.maskbits, True
             r = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
-                            res=dalias, mask=mk, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                            res=dalias if res_c is None else res_c, mask=mk, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
                             bn_sums=bn_in is not None, mask_bits=mkbits,
-                            sums_buf=link.sums_buf if (bn_in is not None and _SUMS_SLOTS) else None)
+                            sums_buf=link.sums_buf if (bn_in is not None and _SUMS_SLOTS) else None,
+                            res_s2=res_c is not None)
+            if r is None and res_c is not None:
+                # no kernel adds the compact form for this shape: expand it and go on as with a full-size gradient
+                dalias = torch.zeros_like(x)
+                dalias[:, ::2, ::2] = res_c
+                res_c = None
+                r = C.dgrad_gpu(dy, cache.transposed(weight, dy.dtype), (x.shape[1], x.shape[2]), stride, pad,
+                                res=dalias, mask=mk, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                                bn_sums=bn_in is not None, mask_bits=mkbits,
+                                sums_buf=link.sums_buf if (bn_in is not None and _SUMS_SLOTS) else None)
             if r is None:
                 if (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
                     # pointwise conv with a filter count the dgrad kernel does not step through (16, 24 in
@@ -398,14 +442,14 @@ class _ConvBnActFn(torch.autograd.Function):
                     dw = dw.to(weight.dtype)
         if dg is not None and gamma is not None and gamma.dtype != dg.dtype:
             dg, db = dg.to(gamma.dtype), db.to(gamma.dtype)
-        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, dg, db, dres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNState,
                 cache: Optional[C.WeightCache] = None, passthrough: bool = False, mask_dx: bool = False,
                 dout_premasked: bool = False, in_link: Optional[BNBackwardLink] = None,
                 out_link: Optional[BNBackwardLink] = None, res_in: Optional[ShortcutLink] = None,
-                res_out: Optional[ShortcutLink] = None):
+                res_out: Optional[ShortcutLink] = None, alias_link: Optional[ShortcutLink] = None):
     """NHWC fused conv + BatchNorm (+residual) (+ReLU).
 
     ``relu``: ``False``, ``True``, or a positive number ``c`` for a ReLU clipped at ``c`` (ReLU6: ``relu=6.0``),
@@ -429,8 +473,9 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNSt
     reductions of this op's BatchNorm backward.  A consumer given ``in_link`` always applies the
     producer's ReLU mask, so the pair stays correct when the sums cannot be produced.
 
-    ``res_out`` / ``res_in``: a :class:`ShortcutLink` shared by a shortcut branch's op (no activation) and the op
-    that takes its output as ``residual``."""
+    ``res_out`` / ``res_in`` / ``alias_link``: a :class:`ShortcutLink` shared by a shortcut branch's op (no
+    activation), the op that takes its output as ``residual`` and the ``passthrough`` op whose alias output is the
+    shortcut's input."""
     if res_in is not None and res_in.affine is not None and (not x.is_cuda or Nm.relu_cap(relu) is not None):
         residual = materialize_shortcut(residual, res_in)
         res_in = None
@@ -448,7 +493,7 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNSt
             return (o, x) if passthrough else o
     return _ConvBnActFn.apply(x, weight, gamma, beta, residual, tuple(stride), tuple(pad), relu, st,
                               cache or C.WeightCache(), passthrough, mask_dx, dout_premasked, in_link, out_link,
-                              res_in, res_out)
+                              res_in, res_out, alias_link)
 
 
 class _MaterializeFn(torch.autograd.Function):

@@ -398,6 +398,7 @@ def test_bottleneck_with_deferred_shortcut_matches_applied(dtype, stride, monkey
     res = []
     for on in (True, False):
         monkeypatch.setattr(fused, "_DEFER_SHORTCUT", on)
+        monkeypatch.setattr(fused, "_COMPACT_SHORTCUT_GRAD", on)   # (stride 2: the shortcut's gradient in compact form)
         blk.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(True)
         out = blk(x)
@@ -411,6 +412,36 @@ def test_bottleneck_with_deferred_shortcut_matches_applied(dtype, stride, monkey
     tol = {torch.float32: 1e-5, torch.float16: 0.12, torch.bfloat16: 0.3}[dtype]
     for a_, b_ in zip(res[0][1:], res[1][1:]):
         assert rel_err(a_, b_) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(16, 16), (15, 9)])
+def test_dgrad_adds_compact_stride2_residual(dtype, hw):
+    """dgrad epilogue with the residual given as the compact gradient of a stride-2 1x1 shortcut (added at the even
+    pixels only), together with the mask and BatchNorm-sum extras, against the full-size residual."""
+    torch.manual_seed(19)
+    H, W = hw
+    N, K, Cc = 3, 64, 256
+    dy = torch.randn(N, H, W, K, device=DEV).to(dtype)
+    w = (torch.randn(K, 1, 1, Cc, device=DEV) / 8).to(dtype)
+    wt = C.krsc_to_crsk(w, dtype)
+    comp = torch.randn(N, (H + 1) // 2, (W + 1) // 2, Cc, device=DEV).to(dtype)
+    full = torch.zeros(N, H, W, Cc, device=DEV, dtype=dtype)
+    full[:, ::2, ::2] = comp
+    bn_in = torch.randn(N, H, W, Cc, device=DEV).to(dtype)
+    sc, sf = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV) * 0.3
+    a = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (0, 0), res=comp, res_s2=True, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                    bn_sums=True)
+    b = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (0, 0), res=full, bn_input=bn_in, bn_scale=sc, bn_shift=sf, bn_sums=True)
+    assert a is not None and b is not None
+    assert torch.equal(a[0], b[0])
+    assert rel_err(a[1].sum(1), b[1].sum(1)) < 1e-5
+    plain = C.dgrad_gpu(dy, wt, (H, W), (1, 1), (0, 0), res=comp, res_s2=True)
+    ref = dy.float().view(-1, K) @ w.view(K, Cc).float()
+    assert rel_err(plain, ref.view(N, H, W, Cc) + full.float()) < TOL[dtype]
+    # a strided conv has no compact form
+    assert C.dgrad_gpu(dy, wt, (2 * H, 2 * W), (2, 2), (0, 0), res=torch.zeros(N, H, W, Cc, device=DEV, dtype=dtype),
+                       res_s2=True) is None
 
 
 def test_batched_weight_transpose_refresh():
