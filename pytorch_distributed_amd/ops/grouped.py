@@ -90,6 +90,20 @@ def _chunked_ok(x: torch.Tensor, weight: torch.Tensor, stride, pad, groups: int)
             and max(Hi, Wi) < 512 and x.numel() * 2 < 2 ** 31 - 1 and os.environ.get("PDA_GROUPED_DENSE", "0") != "1")
 
 
+def chunk_filters_gpu(weight: torch.Tensor, dtype: torch.dtype, with_dgrad: bool, rotate: bool):
+    """One launch for :func:`chunk_filters` and, with ``with_dgrad``, the input-gradient layout
+    ``[K/32, 32 input, 9, 32 output]`` (taps rotated by 180 degrees when ``rotate``: stride-1 layers)."""
+    K, Cg = weight.shape[0], weight.shape[1]
+    w = weight.detach()
+    if w.dtype not in (torch.float32, dtype) or not w.is_contiguous():
+        w = w.to(dtype).contiguous()
+    wf = torch.empty((K // 32, 32, 9, 32), device=w.device, dtype=dtype)
+    wd = torch.empty_like(wf) if with_dgrad else None
+    _lib.check(_lib.lib().pda_grouped_chunk_filters(_lib.dt(wf), _lib.dt(w), w.data_ptr(), wf.data_ptr(), _lib.ptr(wd), K,
+                                                   Cg, int(rotate), _lib.stream()), "pda_grouped_chunk_filters")
+    return wf, wd
+
+
 class _ChunkedGroupedConvFn(torch.autograd.Function):
     """3x3 grouped convolution with ``Cg`` input and output channels per group on the 32-channel-chunk kernels."""
 
@@ -111,14 +125,14 @@ class _ChunkedGroupedConvFn(torch.autograd.Function):
         Ho, Wo = C.out_size(Hi, 3, stride[0], pad[0]), C.out_size(Wi, 3, stride[1], pad[1])
         if Ho < 1 or Wo < 1:
             raise ValueError(f"grouped conv: a 3x3 window does not fit a {Hi}x{Wi} input with padding {pad}")
-        wc = chunk_filters(weight, x.dtype)
+        wc, wd = chunk_filters_gpu(weight, x.dtype, ctx.needs_input_grad[0], stride[0] == 1)
         y = _ChunkedGroupedConvFn._conv(0, x, wc, (N, Ho, Wo, K), stride[0], pad[0])
         if bias is not None:
             l = _lib.lib()
             _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), K,
                                       0, _lib.stream()), "pda_bias_add")
         ctx.save_for_backward(x, weight)
-        ctx.wc = wc
+        ctx.wd = wd
         ctx.cfg = (stride, pad, bias is not None)
         return y
 
@@ -133,15 +147,21 @@ class _ChunkedGroupedConvFn(torch.autograd.Function):
         l = _lib.lib()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            # dx = sum over taps of dy * W^T: the same kernel with each chunk's [output][tap][input] filter transposed
-            dx = _ChunkedGroupedConvFn._conv(1, dy, ctx.wc.transpose(1, 3).contiguous(), tuple(x.shape), stride[0],
-                                             pad[0])
+            if stride[0] == 1:
+                # a stride-1 layer's input gradient is the forward kernel on dy with each chunk's filter rotated by
+                # 180 degrees and transposed, and padding 2 - pad
+                dx = _ChunkedGroupedConvFn._conv(0, dy, ctx.wd, tuple(x.shape), 1, 2 - pad[0])
+            else:
+                # dx = sum over taps of dy * W^T gathered with the stride's parity test: [input][tap][output] filters
+                dx = _ChunkedGroupedConvFn._conv(1, dy, ctx.wd, tuple(x.shape), stride[0], pad[0])
         if ctx.needs_input_grad[1]:
             dwc = torch.zeros((K // 32, 32, 9, 32), device=dy.device, dtype=torch.float32)
             _lib.check(l.pda_grouped_conv3x3_wgrad(_lib.dt(dy), dy.data_ptr(), x.data_ptr(), dwc.data_ptr(), N, Hi, Wi,
                                                    dy.shape[1], dy.shape[2], K, stride[0], pad[0], _lib.stream()),
                        "pda_grouped_conv3x3_wgrad")
-            dw = chunk_diagonal(dwc, Cg, R, S).to(weight.dtype)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _lib.check(l.pda_grouped_chunk_diag(_lib.dt(dw), dwc.data_ptr(), dw.data_ptr(), K, Cg, _lib.stream()),
+                       "pda_grouped_chunk_diag")
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)
             _lib.check(l.pda_colsum(_lib.dt(dy), dy.data_ptr(), db.data_ptr(), dy.numel() // K, K,
