@@ -81,7 +81,7 @@ def main():
             if "f" in a.only and C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=cfg) is not None:
                 t = timeit(lambda: C.fprop_gpu(x, w, (s, s), (pad, pad), stats=not a.no_stats, cfg=cfg), a.iters)
                 best.setdefault("fprop", []).append((t, cfg))
-            if "d" in a.only and cfg != 33 and C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg) is not None:
+            if "d" in a.only and cfg not in (33, 34) and C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg) is not None:
                 t = timeit(lambda: C.dgrad_gpu(dy, wt, (h, h), (s, s), (pad, pad), cfg=cfg), a.iters)
                 best.setdefault("dgrad", []).append((t, cfg))
         dw = torch.zeros(co, k, k, ci, device=dev)

@@ -61,6 +61,7 @@ _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7, 13)   # 13: 256x128 ring on 2
 # 33: the A-stationary pointwise kernel (csrc/kernels/pointwise_astat.hip): unpadded 1x1, 64 / 128 / 256 / 512 input
 # channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
 _FPROP_PW_CFG = 33
+_FPROP_C64_CFG = 34   # weight-stationary 3x3 on 64 -> 64 channels (csrc/kernels/conv3x3_c64.hip)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
 _WGRAD_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 13)  # wgrad: 1/2/3 = 128x128, 64x64, 64x128; 12/13 = 256x128, 128x256
@@ -154,15 +155,38 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
              and x.element_size() == 2 and Ci in (64, 128, 256, 512) and K % 8 == 0)
     if cfg == _FPROP_PW_CFG and not pw_ok:
         return None
+    c64_ok = (geom is None and R == 3 and S == 3 and Ci == 64 and K == 64 and stride[0] == stride[1] and stride[0] in (1, 2)
+              and pad[0] == pad[1] and 0 <= pad[0] <= 2 and res is None and not relu and bias is None
+              and in_affine is None and x.element_size() == 2 and x.numel() * 2 < 2 ** 31 - 1
+              and (not stats or stats_buf is None or True))
+    if cfg == _FPROP_C64_CFG and not c64_ok:
+        return None
     if cfg == 0 and backends.benchmark and geom is None:
         cands = _FPROP_XF_CFGS if in_affine is not None else (_FPROP_CFGS if res is None else _DGRAD_EX_CFGS)
         if pw_ok:
             cands = cands + (_FPROP_PW_CFG,)
+        if c64_ok:
+            cands = cands + (_FPROP_C64_CFG,)
         cfg = _tuned_cfg("fprop", (x.dtype, N, Hi, Wi, Ci, K, R, S, tuple(stride), tuple(pad), res is not None, stats,
                                    in_affine is not None), cands,
                          lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias,
                                              in_affine))
     cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
+    if cfg == _FPROP_C64_CFG:
+        y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
+        part = None
+        if stats:
+            rows = l.pda_conv3x3_c64_rows(N, Ho, Wo, stride[0])
+            if rows <= 0:
+                return None
+            part = torch.empty((2, rows, K), device=x.device, dtype=torch.float32)
+        rc = l.pda_conv3x3_c64(_lib.dt(x), x.data_ptr(), w_krsc.data_ptr(), y.data_ptr(),
+                               part[0].data_ptr() if stats else None, part[1].data_ptr() if stats else None, N, Hi, Wi,
+                               Ho, Wo, stride[0], pad[0], _lib.stream())
+        if rc < 0:
+            return None
+        _lib.check(rc, "pda_conv3x3_c64")
+        return (y, part[0], part[1]) if stats else y
     y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
     psum = psq = None
     slots = 0

@@ -444,6 +444,31 @@ def test_dgrad_adds_compact_stride2_residual(dtype, hw):
                        res_s2=True) is None
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,h,w,stride,pad", [(3, 56, 56, 1, 1), (2, 13, 37, 1, 1), (5, 7, 7, 1, 1), (2, 20, 70, 1, 0),
+                                              (2, 30, 30, 2, 1), (1, 9, 150, 1, 2)])
+def test_weight_stationary_3x3_on_64_channels(dtype, n, h, w, stride, pad):
+    """conv3x3_c64.hip (weights resident in registers, halo tile in LDS) against the fp32 convolution of the same
+    16-bit operands, with the BatchNorm statistics of the rounded output."""
+    torch.manual_seed(23)
+    x = torch.randn(n, h, w, 64, device=DEV).to(dtype)
+    wk = (torch.randn(64, 3, 3, 64, device=DEV) / 24).to(dtype)
+    r = C.fprop_gpu(x, wk, (stride, stride), (pad, pad), stats=True, cfg=C._FPROP_C64_CFG)
+    assert r is not None
+    y, psum, psq = r
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wk.float().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL[dtype]
+    yf = y.float().reshape(-1, 64)
+    assert rel_err(psum.sum(0), yf.sum(0)) < 1e-3
+    assert rel_err(psq.sum(0), (yf * yf).sum(0)) < 1e-4
+    y2 = C.fprop_gpu(x, wk, (stride, stride), (pad, pad), cfg=C._FPROP_C64_CFG)
+    assert torch.equal(y2, y)
+    # other channel counts are not this kernel's
+    assert C.fprop_gpu(x[..., :32].contiguous(), wk[:, :, :, :32].contiguous(), (1, 1), (1, 1), cfg=C._FPROP_C64_CFG) is None
+
+
 def test_batched_weight_transpose_refresh():
     """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
     torch.manual_seed(41)
