@@ -76,6 +76,15 @@ __device__ __forceinline__ typename TailMfma<T>::frag tail_tr_read(const unsigne
   return __builtin_bit_cast(typename TailMfma<T>::frag, v);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory: every wave would wait
+// for the tile's dX / dy3 stores (a trip to memory) before the next tile's images may be written.
+__device__ __forceinline__ void tail_lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));   // lgkmcnt(0) only
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // CO / CI: conv3's output / input channels (256 / 64 or 512 / 128).  WGRAD: the weight gradient is part of the pass;
 // without it (the 128 -> 512 stage: 512 x 128 fp32 accumulators plus the weight fragments do not fit a workgroup's
 // registers) dy3 is also stored and the ring weight-gradient kernel reads it - still one pass over dz / y3 less.
@@ -207,7 +216,7 @@ tail_bwd_kernel(TailArgs a) {
       }
       if (WGRAD) *reinterpret_cast<frag*>(imgA + (rowx + RSX * v) * PA + cvx * 16) = a2[v];
     }
-    __syncthreads();
+    tail_lds_barrier();
     // ---- the next tile's operands travel while this one computes
     if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
 
@@ -242,7 +251,7 @@ tail_bwd_kernel(TailArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         *reinterpret_cast<T*>(stg + ((rb0 + r) * 16 + 4 * l4 + e) * PS + (cb * 16 + l15) * 2) = ElemTraits<T>::from_f32(dacc[r][e]);
-    __syncthreads();   // also: every wave is done reading this tile's images
+    tail_lds_barrier();   // also: every wave is done reading this tile's images
 #pragma unroll
     for (int v = 0; v < NVX; ++v) {
       Vec16<T> dxv = *reinterpret_cast<const Vec16<T>*>(stg + (rowx + RSX * v) * PS + cvx * 16);

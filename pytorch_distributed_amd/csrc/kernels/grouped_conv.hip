@@ -154,6 +154,15 @@ struct GLArgs {
   int ntiles;
 };
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also fences global memory: every wave would wait
+// for its output stores of the tile before the next halo may be written).
+__device__ __forceinline__ void gconv_lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));   // lgkmcnt(0) only
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 gconv_lds_kernel(GLArgs a) {
@@ -223,7 +232,7 @@ gconv_lds_kernel(GLArgs a) {
         if (v < nvx) *reinterpret_cast<Vec16<T>*>(lds + (v >> 4) * PP + (v & 15) * 16) = val[u];
       }
     }
-    __syncthreads();
+    gconv_lds_barrier();
     if (wave_live) {
       f32x16 acc[2];
 #pragma unroll
@@ -259,7 +268,7 @@ gconv_lds_kernel(GLArgs a) {
         }
       }
     }
-    __syncthreads();   // every wave is done reading this tile's halo
+    gconv_lds_barrier();   // every wave is done reading this tile's halo
   }
 #endif
 }
