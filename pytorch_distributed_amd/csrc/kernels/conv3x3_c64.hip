@@ -24,7 +24,11 @@ struct C64Args {
   const void* w;   // [64 result channels][9 taps][64 reduced channels]
   void* y;         // [N][Ho][Wo][64]
   float* psum;     // [workgroups][64] per-workgroup column sums of the (rounded) output, or null
-  float* psq;      // ... and of its squares
+  float* psq;      // ... and of its squares (MASKED kernels: of output * bnc)
+  const void* bnc;        // MASKED kernels (a dgrad with the producer's BatchNorm + ReLU backward folded in): [N][Ho][Wo][64],
+  const float* bn_scale;  // the producing layer's conv output; the result is zeroed where bnc * bn_scale + bn_shift <= 0
+  const float* bn_shift;
+  int flip;        // the filter is used rotated by 180 degrees (tap 8 - t): the input gradient of a stride-1 layer
   long long x_bytes;
   int N, Hi, Wi, Ho, Wo;
   int stride, pad;
@@ -86,7 +90,9 @@ __device__ __forceinline__ void c64_wait_reads(int pending) {
   }
 }
 
-template <typename T, bool STATS>
+// STATS: column sums of the output (and of its squares, or with MASKED of output * bnc) per workgroup.
+// MASKED: see C64Args::bnc (implies STATS).
+template <typename T, bool STATS, bool MASKED = false>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_c64_kernel(C64Args a) {
   constexpr int NT = 256, CH = 64;
@@ -105,7 +111,7 @@ conv3x3_c64_kernel(C64Args a) {
     const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + (long long)(oc * 32 + l31) * 9 * CH + lh * 8;
 #pragma unroll
     for (int k = 0; k < 36; ++k) {
-      const Vec16<T> v = load16(W + (k >> 2) * CH + (k & 3) * 16);
+      const Vec16<T> v = load16(W + (a.flip ? 8 - (k >> 2) : (k >> 2)) * CH + (k & 3) * 16);
       wf[k] = __builtin_bit_cast(frag, v);
     }
   }
@@ -154,6 +160,11 @@ conv3x3_c64_kernel(C64Args a) {
   constexpr int RP = 36;   // floats per lane: 32 values + padding (144 bytes: conflict-free 16-byte accesses)
   float* red = reinterpret_cast<float*>(lds + a.HR * a.HW * PPX);   // [4 waves][64 lanes][RP]
   float* mine = red + (wid * 64 + lane) * RP;
+  float* tab = red + 4 * 64 * RP;   // MASKED: [2][64] scale, shift
+  if (MASKED) {
+    if (t < 128) tab[t] = t < 64 ? a.bn_scale[t] : a.bn_shift[t - 64];   // (read after the first barrier of the loop)
+  }
+  const T* __restrict__ Bc = reinterpret_cast<const T*>(a.bnc);
   if (STATS) {
 #pragma unroll
     for (int g = 0; g < 32; g += 4) *reinterpret_cast<f32x4*>(mine + g) = f32x4{0.f, 0.f, 0.f, 0.f};   // (own slots: no barrier)
@@ -169,6 +180,17 @@ conv3x3_c64_kernel(C64Args a) {
       if (v < nvx) *reinterpret_cast<u32x4*>(lds + (v >> 3) * PPX + (v & 7) * 16) = pv[u];
     }
     c64_lds_barrier();
+    // this tile's pixel (the lane's column of the result)
+    const int n = tile / tiles_img, ti = tile - n * tiles_img;
+    const int th = ti / a.tiles_w;
+    const int ho = th * a.TR + ptr, wo = (ti - th * a.tiles_w) * a.TW + ptw;
+    const bool pix_ok = ho < a.Ho && wo < a.Wo;
+    const long long pix = pix_ok ? (((long long)n * a.Ho + ho) * a.Wo + wo) * CH + oc * 32 + 4 * lh : 0;
+    u32x2 bcv[MASKED ? 4 : 1];
+    if (MASKED) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) bcv[qd] = *reinterpret_cast<const u32x2*>(Bc + pix + qd * 8);
+    }
     // the next tile's halo travels while this one computes (past the end: the last tile once more, unused)
     if (!(a.ablate & 4)) fetch(min(tile + nslots, a.ntiles - 1));
     __builtin_amdgcn_sched_barrier(0);
@@ -195,22 +217,33 @@ conv3x3_c64_kernel(C64Args a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] += acc1[g];
     // C/D map of the 32x32 MFMA: column (pixel) lane & 31, rows (channels) (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5)
-    const int n = tile / tiles_img, ti = tile - n * tiles_img;
-    const int th = ti / a.tiles_w;
-    const int ho = th * a.TR + ptr, wo = (ti - th * a.tiles_w) * a.TW + ptw;
-    if (ho < a.Ho && wo < a.Wo && !(a.ablate & 1)) {
-      T* __restrict__ yo = Y + (((long long)n * a.Ho + ho) * a.Wo + wo) * CH + oc * 32 + 4 * lh;
+    if (pix_ok && !(a.ablate & 1)) {
+      T* __restrict__ yo = Y + pix;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         VecN<T, 4> o;
         f32x4 sv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msf = {0.f, 0.f, 0.f, 0.f};
+        VecN<T, 4> cf4;
+        if (MASKED) {
+          msc = *reinterpret_cast<const f32x4*>(tab + oc * 32 + 4 * lh + qd * 8);
+          msf = *reinterpret_cast<const f32x4*>(tab + 64 + oc * 32 + 4 * lh + qd * 8);
+          *reinterpret_cast<u32x2*>(&cf4) = bcv[qd];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          o.v[e] = ElemTraits<T>::from_f32(acc[qd * 4 + e]);
+          float r = acc[qd * 4 + e];
+          float cf = 0.f;
+          if (MASKED) {
+            // ReLU backward of the layer that produced this conv's forward input, mask recomputed from its conv output
+            cf = ElemTraits<T>::to_f32(cf4.v[e]);
+            if (!(cf * msc[e] + msf[e] > 0.f)) r = 0.f;
+          }
+          o.v[e] = ElemTraits<T>::from_f32(r);
           if (STATS) {
             const float fv = ElemTraits<T>::to_f32(o.v[e]);
             sv[e] = fv;
-            qv[e] = fv * fv;
+            qv[e] = MASKED ? fv * cf : fv * fv;
           }
         }
         *reinterpret_cast<u32x2*>(yo + qd * 8) = *reinterpret_cast<const u32x2*>(&o);
@@ -279,19 +312,14 @@ PDA_EXPORT int pda_conv3x3_c64_rows(int N, int Ho, int Wo, int stride) {
   return c64_workgroups(tiles);
 }
 
-// y[N][Ho][Wo][64] = 3x3 convolution (stride 1 or 2, padding 0..2) of x[N][Hi][Wi][64] with w[64][3][3][64] (output
-// channel, taps, input channel); psum / psq (both or neither): fp32 [pda_conv3x3_c64_rows()][64] per-workgroup sums of
-// the rounded output and of its squares.  <0: not covered.
-PDA_EXPORT int pda_conv3x3_c64(int dtype, const void* x, const void* w, void* y, float* psum, float* psq, int N, int Hi,
-                               int Wi, int Ho, int Wo, int stride, int pad, hipStream_t stream) {
+static int c64_launch(int dtype, C64Args& a, int N, int Hi, int Wi, int Ho, int Wo, int stride, int pad, bool masked,
+                      hipStream_t stream) {
   if (dtype != PDA_F16 && dtype != PDA_BF16) return -6;
   if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (stride != 1 && stride != 2) || pad < 0 || pad > 2) return -1;
   if ((Hi + 2 * pad - 3) / stride + 1 != Ho || (Wi + 2 * pad - 3) / stride + 1 != Wo) return -1;
-  if (!x || !w || !y || ((psum == nullptr) != (psq == nullptr))) return -11;
-  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0) return -5;
-  C64Args a;
-  a.x = x; a.w = w; a.y = y; a.psum = psum; a.psq = psq; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo;
-  a.stride = stride; a.pad = pad;
+  if (!a.x || !a.w || !a.y || ((a.psum == nullptr) != (a.psq == nullptr))) return -11;
+  if ((((uintptr_t)a.x | (uintptr_t)a.w | (uintptr_t)a.y | (uintptr_t)a.bnc) & 15) != 0) return -5;
+  a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = pad;
   a.x_bytes = (long long)N * Hi * Wi * 64 * 2;
   if (a.x_bytes >= 0x7fffffffLL) return -4;
   if (!c64_geometry(a, Ho, Wo, stride)) return -1;
@@ -302,14 +330,44 @@ PDA_EXPORT int pda_conv3x3_c64(int dtype, const void* x, const void* w, void* y,
   a.ablate = ablate;
   const int nwg = c64_workgroups(tiles);
   int lds_bytes = a.HR * a.HW * (64 * 2 + 16);
-  if (psum != nullptr) lds_bytes += 4 * 64 * 36 * 4;   // the statistics slots behind the halo
-#define PDA_C64_LAUNCH(T, ST) hipLaunchKernelGGL((conv3x3_c64_kernel<T, ST>), dim3(nwg), dim3(256), lds_bytes, stream, a)
+  if (a.psum != nullptr) lds_bytes += 4 * 64 * 36 * 4 + 2 * 64 * 4;   // the statistics slots and the mask table behind the halo
+#define PDA_C64_LAUNCH(T, ST, MK) hipLaunchKernelGGL((conv3x3_c64_kernel<T, ST, MK>), dim3(nwg), dim3(256), lds_bytes, stream, a)
   if (dtype == PDA_F16) {
-    if (psum) PDA_C64_LAUNCH(f16, true); else PDA_C64_LAUNCH(f16, false);
+    if (masked) PDA_C64_LAUNCH(f16, true, true);
+    else if (a.psum) PDA_C64_LAUNCH(f16, true, false);
+    else PDA_C64_LAUNCH(f16, false, false);
   } else {
-    if (psum) PDA_C64_LAUNCH(bf16, true); else PDA_C64_LAUNCH(bf16, false);
+    if (masked) PDA_C64_LAUNCH(bf16, true, true);
+    else if (a.psum) PDA_C64_LAUNCH(bf16, true, false);
+    else PDA_C64_LAUNCH(bf16, false, false);
   }
 #undef PDA_C64_LAUNCH
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// y[N][Ho][Wo][64] = 3x3 convolution (stride 1 or 2, padding 0..2) of x[N][Hi][Wi][64] with w[64][3][3][64] (output
+// channel, taps, input channel); psum / psq (both or neither): fp32 [pda_conv3x3_c64_rows()][64] per-workgroup sums of
+// the rounded output and of its squares.  <0: not covered.
+PDA_EXPORT int pda_conv3x3_c64(int dtype, const void* x, const void* w, void* y, float* psum, float* psq, int N, int Hi,
+                               int Wi, int Ho, int Wo, int stride, int pad, hipStream_t stream) {
+  C64Args a;
+  a.x = x; a.w = w; a.y = y; a.psum = psum; a.psq = psq; a.bnc = nullptr; a.bn_scale = nullptr; a.bn_shift = nullptr;
+  a.flip = 0;
+  return c64_launch(dtype, a, N, Hi, Wi, Ho, Wo, stride, pad, false, stream);
+}
+
+// Input gradient of a stride-1 3x3 convolution on 64 -> 64 channels with the backward of the producing layer's
+// BatchNorm + ReLU folded in: dx[N][Hi][Wi][64] = (dy[N][Ho][Wo][64] conv^T w) * (bnc * bn_scale + bn_shift > 0), with
+// wt[64 input channels][3][3][64 output channels] (the CRSK transpose), bnc[N][Hi][Wi][64] the producing layer's conv
+// output; psum / psq: fp32 [pda_conv3x3_c64_rows(N, Hi, Wi, 1)][64] per-workgroup sums of dx and of dx * bnc.
+PDA_EXPORT int pda_conv3x3_c64_dgrad_masked(int dtype, const void* dy, const void* wt, void* dx, const void* bnc,
+                                            const float* bn_scale, const float* bn_shift, float* psum, float* psq, int N,
+                                            int Ho, int Wo, int Hi, int Wi, int pad, hipStream_t stream) {
+  if (!bnc || !bn_scale || !bn_shift || !psum || !psq) return -11;
+  C64Args a;
+  a.x = dy; a.w = wt; a.y = dx; a.psum = psum; a.psq = psq; a.bnc = bnc; a.bn_scale = bn_scale; a.bn_shift = bn_shift;
+  a.flip = 1;
+  // the forward-type kernel on dy: filter rotated by 180 degrees, padding 2 - pad
+  return c64_launch(dtype, a, N, Ho, Wo, Hi, Wi, 1, 2 - pad, true, stream);
 }

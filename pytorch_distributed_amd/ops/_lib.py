@@ -53,6 +53,7 @@ _SIGS = {
     "pda_grouped_conv3x3": [c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv3x3_c64_rows": [c_i, c_i, c_i, c_i],
     "pda_conv3x3_c64": [c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pda_conv3x3_c64_dgrad_masked": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_grouped_chunk_filters": [c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "pda_grouped_chunk_diag": [c_i, c_p, c_p, c_i, c_i, c_p],
     "pda_grouped_conv3x3_wgrad": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

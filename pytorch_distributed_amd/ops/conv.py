@@ -261,16 +261,40 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
     N, Ho, Wo, K = dy.shape
     C, R, S = w_crsk.shape[0], w_crsk.shape[1], w_crsk.shape[2]
     Hi, Wi = in_hw
+    # the weight-stationary 64 -> 64 kernel takes the dgrad of a stride-1 layer with exactly the "producer's BatchNorm
+    # + ReLU backward" extras (mask recomputed from bn_input, sums of dx and dx * bn_input)
+    c64_ok = (R == 3 and S == 3 and C == 64 and K == 64 and tuple(stride) == (1, 1) and pad[0] == pad[1]
+              and 0 <= pad[0] <= 2 and dy.element_size() == 2 and res is None and mask is None and bn_input is not None
+              and bn_scale is not None and bn_shift is not None and bn_sums and not res_s2
+              and dy.numel() * 2 < 2 ** 31 - 1)
+    if cfg == _FPROP_C64_CFG and not c64_ok:
+        return None
     if cfg == 0 and backends.benchmark:
         extras = res is not None or mask is not None or bn_input is not None
         cfg = _tuned_cfg("dgrad", (dy.dtype, N, Ho, Wo, K, C, R, S, Hi, Wi, tuple(stride), tuple(pad), res is not None,
                                    mask is not None, bn_input is not None, bn_scale is not None, bn_sums, mask_bits,
                                    res_s2),
-                         _DGRAD_EX_CFGS if extras else _FPROP_CFGS,
+                         (_DGRAD_EX_CFGS if extras else _FPROP_CFGS) + ((_FPROP_C64_CFG,) if c64_ok else ()),
                          lambda c: dgrad_gpu(dy, w_crsk, in_hw, stride, pad, res, c or 1 << 30, mask, bn_input, bn_scale,
                                              bn_shift, bn_sums, mask_bits, None, res_s2))
     cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
+    if cfg == _FPROP_C64_CFG:
+        if (bn_input.shape != dx.shape or bn_input.dtype != dx.dtype or not bn_input.is_contiguous()
+                or bn_scale.dtype != torch.float32 or bn_shift.dtype != torch.float32):
+            raise ValueError(f"dgrad_gpu: bn_input must be a contiguous {tuple(dx.shape)} {dx.dtype} tensor")
+        rows = l.pda_conv3x3_c64_rows(N, Hi, Wi, 1)
+        if rows <= 0:
+            return None
+        sums = torch.empty((2, rows, C), device=dy.device, dtype=torch.float32)
+        rc = l.pda_conv3x3_c64_dgrad_masked(_lib.dt(dy), dy.data_ptr(), w_crsk.data_ptr(), dx.data_ptr(),
+                                            bn_input.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(),
+                                            sums[0].data_ptr(), sums[1].data_ptr(), N, Ho, Wo, Hi, Wi, pad[0],
+                                            _lib.stream())
+        if rc < 0:
+            return None
+        _lib.check(rc, "pda_conv3x3_c64_dgrad_masked")
+        return dx, sums
     for name, t in (("res", None if res_s2 else res), ("mask", None if mask_bits else mask), ("bn_input", bn_input)):
         if t is not None and (t.shape != dx.shape or t.dtype != dx.dtype or not t.is_contiguous()):
             raise ValueError(f"dgrad_gpu: {name} must be a contiguous {tuple(dx.shape)} {dx.dtype} tensor")

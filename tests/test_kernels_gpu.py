@@ -469,6 +469,34 @@ def test_weight_stationary_3x3_on_64_channels(dtype, n, h, w, stride, pad):
     assert C.fprop_gpu(x[..., :32].contiguous(), wk[:, :, :, :32].contiguous(), (1, 1), (1, 1), cfg=C._FPROP_C64_CFG) is None
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,h,w,pad", [(3, 56, 56, 1), (2, 13, 37, 1), (4, 7, 7, 1), (2, 20, 40, 0)])
+def test_weight_stationary_3x3_masked_dgrad(dtype, n, h, w, pad):
+    """The 64 -> 64 kernel as the input gradient of a stride-1 layer with the producer's BatchNorm + ReLU backward in
+    its epilogue, against the tiled kernel with the same extras and against fp32."""
+    torch.manual_seed(24)
+    ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+    dy = torch.randn(n, ho, wo, 64, device=DEV).to(dtype)
+    wk = (torch.randn(64, 3, 3, 64, device=DEV) / 24).to(dtype)
+    wt = C.krsc_to_crsk(wk, dtype)
+    bn_in = torch.randn(n, h, w, 64, device=DEV).to(dtype)
+    sc, sf = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3
+    a = C.dgrad_gpu(dy, wt, (h, w), (1, 1), (pad, pad), bn_input=bn_in, bn_scale=sc, bn_shift=sf, bn_sums=True,
+                    cfg=C._FPROP_C64_CFG)
+    b = C.dgrad_gpu(dy, wt, (h, w), (1, 1), (pad, pad), bn_input=bn_in, bn_scale=sc, bn_shift=sf, bn_sums=True, cfg=1)
+    assert a is not None and b is not None
+    ref = torch.nn.grad.conv2d_input((n, 64, h, w), wk.float().permute(0, 3, 1, 2), dy.float().permute(0, 3, 1, 2),
+                                     stride=1, padding=pad).permute(0, 2, 3, 1)
+    ref = ref * ((bn_in.float() * sc + sf) > 0)
+    assert rel_err(a[0], ref) < TOL[dtype]
+    assert rel_err(a[0], b[0]) < 2e-3 if dtype == torch.float16 else rel_err(a[0], b[0]) < 1.5e-2
+    g = a[0].float().reshape(-1, 64)
+    assert rel_err(a[1][0].sum(0), g.sum(0)) < 2e-3
+    assert rel_err(a[1][1].sum(0), (g * bn_in.float().reshape(-1, 64)).sum(0)) < 2e-3
+    # without exactly these extras the candidate is refused
+    assert C.dgrad_gpu(dy, wt, (h, w), (1, 1), (pad, pad), cfg=C._FPROP_C64_CFG) is None
+
+
 def test_batched_weight_transpose_refresh():
     """After an optimizer-style in-place update every cached CRSK transpose is refreshed by one launch."""
     torch.manual_seed(41)
