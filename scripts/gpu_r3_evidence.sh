@@ -4,7 +4,7 @@
 set -o pipefail
 mkdir -p gpurun_out
 bash scripts/gpu_prof_b400.sh || exit 1
-timeout -k 10 600 python -u benchmarks/conv_bench.py --batch 400 --iters 10 --cfgs 0,1,2,9,12,5,6,7,13,33 --wcfgs 0,1,12,65,66,68,69,70 --out gpurun_out/conv_layers_b400_r3.csv > gpurun_out/conv_layers_b400_r3.txt 2>&1 || { tail -n 20 gpurun_out/conv_layers_b400_r3.txt; exit 1; }
+timeout -k 10 600 python -u benchmarks/conv_bench.py --batch 400 --iters 10 --cfgs 0,1,2,9,12,5,6,7,13,33,34 --wcfgs 0,1,12,65,66,68,69,70 --out gpurun_out/conv_layers_b400_r3.csv > gpurun_out/conv_layers_b400_r3.txt 2>&1 || { tail -n 20 gpurun_out/conv_layers_b400_r3.txt; exit 1; }
 tail -n 1 gpurun_out/conv_layers_b400_r3.txt
 run() { # name, args
   local name=$1; shift
