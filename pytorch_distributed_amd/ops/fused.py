@@ -64,11 +64,13 @@ _SIDE_STREAM_MIN_FLOP = float(os.environ.get("PDA_WGRAD_STREAM_MIN_GFLOP", "8"))
 # Block-output ReLU masks travel to the consuming conv's dgrad epilogue as sign bits (BNBackwardLink.maskbits).
 _MASK_BITS = os.environ.get("PDA_RELU_MASK_BITS", "1") == "1"
 
-# Normalise-on-load between a conv+BatchNorm+ReLU and its single consumer (see BNBackwardLink.defer).
-# On by default for fp16 only: bf16 has no packed FMA, its on-load normalisation runs in fp32 and costs more than
-# the pass it saves (ResNet-50, batch 400: 34.1 vs 33.5 ms per step); PDA_DEFER_BN_APPLY=all forces it for both.
-_DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") in ("1", "all")
-_DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") == "all"
+# Normalise-on-load between a conv+BatchNorm+ReLU and its single consumer (see BNBackwardLink.defer): "1" / "all" =
+# both 16-bit types, "fp16" = fp16 only, "0" = off.  bf16 has no packed FMA, so its on-load normalisation runs in
+# fp32, and with the tiled kernels alone that cost more than the pass it saved (ResNet-50, batch 400: 34.1 vs
+# 33.5 ms per step) - but the A-stationary pointwise kernel and the fused bottleneck-tail backward only exist
+# behind this hand-off: 30.25 -> 28.7 ms per step in bf16 with it on.
+_DEFER_APPLY = os.environ.get("PDA_DEFER_BN_APPLY", "1") in ("1", "all", "fp16")
+_DEFER_ALL_16BIT = os.environ.get("PDA_DEFER_BN_APPLY", "1") in ("1", "all")
 
 
 # Backward of a bottleneck's last 1x1 conv on the 64 -> 256 geometry: BatchNorm backward apply + dgrad + wgrad in one

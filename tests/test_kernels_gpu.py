@@ -1568,7 +1568,7 @@ def test_deferred_batchnorm_apply_block_matches_two_pass(kind, dtype, mask, monk
     from pytorch_distributed_amd.models.resnet import Bottleneck, BasicBlock
     import torch.nn as tnn
     monkeypatch.setattr(R, "_DEFER_MASK", mask)
-    monkeypatch.setattr(fused, "_DEFER_ALL_16BIT", True)   # bf16 defers only on request (it is slower there)
+    monkeypatch.setattr(fused, "_DEFER_ALL_16BIT", True)   # (the default; PDA_DEFER_BN_APPLY=fp16 would leave bf16 out)
     torch.manual_seed(23)
     if kind == "basic":
         blk = BasicBlock(64, 64)
