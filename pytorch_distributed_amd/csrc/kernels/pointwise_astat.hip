@@ -42,6 +42,16 @@ struct PWArgs {
   int nch, nx, ny;       // output channels per workgroup, row tiles, channel chunks
   int stat_slots;
   int stream_out;
+  // MAT kernels: x is the conv output y3 of the previous residual block's last layer (dense [M][K]) and this kernel
+  // finishes that block on the way in: out = relu(y3 * mat_scale + mat_shift + mat_res [* mat_res_scale]) is computed
+  // in fp32 on the A rows, rounded, stored to mat_out ([M][K]) with its sign bits (mat_mask: one byte per 16-byte
+  // vector) and used as the operand - the block-end pass and this conv's read of its result become one
+  const void* mat_res;
+  const float* mat_scale;
+  const float* mat_shift;
+  const float* mat_res_scale;   // (ones for an identity shortcut)
+  void* mat_out;
+  unsigned char* mat_mask;
 };
 
 template <typename T> struct MfmaPW;
@@ -93,9 +103,11 @@ template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b
 }
 
 // KS: K / 64.  MI: 32-row blocks per wave (2, or 1 when the K = 512 fragments of two blocks would not fit).
-template <typename T, int KS, int MI, bool XF>
+// MODE: 0 = x as it is, 1 (XF) = relu(x * in_scale + in_shift), 2 (MAT) = see PWArgs::mat_res.
+template <typename T, int KS, int MI, int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 pw_fprop_kernel(PWArgs a) {
+  constexpr bool XF = MODE == 1;
   constexpr int KK = KS * 4;               // 16-deep MFMA groups along K
   constexpr int NI = 2;                    // a tile is 64 output channels
   constexpr int STAGES = 4, STEP_BYTES = 64 * 128, PIECES = 2;   // ring step: 64 weight rows x 64 k
@@ -127,6 +139,7 @@ pw_fprop_kernel(PWArgs a) {
   const auto rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   frag afr[MI][KK];
   bool rok[MI];
+  unsigned vos[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int r = m0 + i * 32 + l31;
@@ -141,9 +154,12 @@ pw_fprop_kernel(PWArgs a) {
       off = n * a.sn + ho * a.sh + wo * a.sw;
     }
     const unsigned vo = rok[i] ? (unsigned)(off * 2 + lh * 16) : OOB;
+    vos[i] = vo;
+    if constexpr (MODE != 2) {
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-      afr[i][kk] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, vo + kk * 32, 0, 0));
+      for (int kk = 0; kk < KK; ++kk)
+        afr[i][kk] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, vo + kk * 32, 0, 0));
+    }
   }
 
   // ---- weight ring: a wave instruction fills 1 KiB = 8 rows of a step's [64 rows][64 k] image; 16-byte chunks are
@@ -186,6 +202,64 @@ pw_fprop_kernel(PWArgs a) {
         afr[i][kk] = rok[i] ? v : zero;   // rows past M stay exact zeros (statistics)
       }
     }
+  }
+
+  if constexpr (MODE == 2) {
+    // The previous block's last pass: BatchNorm + shortcut + ReLU in fp32 (as bn_apply_kernel), 64 channels at a
+    // time, with the lanes in row-vector roles (lane -> 16-byte vector lane & 7 of rows q * 8 + lane / 8): whole
+    // 128-byte lines per row are read from y3 and the shortcut and written to `out`, one sign byte per vector goes to
+    // the mask, and the rounded values pass through this wave's staging area into MFMA operand layout (the lane = row
+    // layout of the direct A loads would read and write 16 bytes per row and instruction: measured 20 % slower than
+    // the two separate kernels).  Rows past M stay exact zeros (statistics).
+    const auto rsrcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.mat_res), 0, (int)a.x_bytes, 0x00020000);
+    const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc(a.mat_out, 0, (int)a.x_bytes, 0x00020000);
+    const auto rsrcM = __builtin_amdgcn_make_buffer_rsrc(a.mat_mask, 0, (int)(a.x_bytes / 16), 0x00020000);
+    const int cv = lane & 7, rg = lane >> 3;
+    const unsigned stg_w = lds_base + RING + wid * STG;
+    const unsigned char* stg_r = lds + RING + wid * STG;
+    static_for(std::make_integer_sequence<int, KS>{}, [&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      const int c0 = ks * 64 + cv * 8;
+      const f32x4 sc0 = *reinterpret_cast<const f32x4*>(a.mat_scale + c0), sc1 = *reinterpret_cast<const f32x4*>(a.mat_scale + c0 + 4);
+      const f32x4 sf0 = *reinterpret_cast<const f32x4*>(a.mat_shift + c0), sf1 = *reinterpret_cast<const f32x4*>(a.mat_shift + c0 + 4);
+      // (always a table - ones for a plain identity shortcut: a run-time branch inside this unrolled code spills)
+      const f32x4 rs0 = *reinterpret_cast<const f32x4*>(a.mat_res_scale + c0), rs1 = *reinterpret_cast<const f32x4*>(a.mat_res_scale + c0 + 4);
+      frag yv[WROWS / 8], rv[WROWS / 8];
+      unsigned go[WROWS / 8];
+#pragma unroll
+      for (int q = 0; q < WROWS / 8; ++q) {
+        const int m = m0 + q * 8 + rg;
+        go[q] = m < a.M ? (unsigned)(((long long)m * K + c0) * 2) : OOB;
+        yv[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, go[q], 0, 0));
+        rv[q] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrcR, go[q], 0, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < WROWS / 8; ++q) {
+        frag o;
+        unsigned bits = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float scv = e < 4 ? sc0[e & 3] : sc1[e & 3], sfv = e < 4 ? sf0[e & 3] : sf1[e & 3];
+          const float rsv = e < 4 ? rs0[e & 3] : rs1[e & 3];
+          const float f = fmaxf((float)yv[q][e] * scv + sfv + (float)rv[q][e] * rsv, 0.f);
+          o[e] = (T)f;
+          bits |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+        }
+        if (go[q] == OOB) o = frag{};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrcO, go[q], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rsrcM, go[q] == OOB ? OOB : go[q] >> 4, 0, 0);
+        lds_write_b128<0>(stg_w + (q * 8 + rg) * SP + cv * 16, __builtin_bit_cast(u32x4, o));
+      }
+      // back in operand layout (LDS operations of a wave run in order: the reads see the writes)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          afr[i][ks * 4 + kk] = *reinterpret_cast<const frag*>(stg_r + (i * 32 + l31) * SP + (kk * 2 + lh) * 16);
+      // (one 64-channel slice at a time: the staging area is reused, and hoisting every slice's requests spills)
+      __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8));   // lgkmcnt(0): the reads above, before the next writes
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 
   // fragment addresses of the weight tile: row = output channel j * 32 + l31, chunk (kk * 2 + lh) ^ swizzle
@@ -344,10 +418,17 @@ int launch_pw(PWArgs a, hipStream_t st) {
   a.ny = (a.N + nch - 1) / nch;
   const long long nwg = (long long)a.nx * a.ny;
   if (nwg > 0x7fffffffLL) return -4;
-  if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((pw_fprop_kernel<T, KS, MI, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+  if (a.mat_res != nullptr) {
+    if constexpr (KS == 4 || KS == 8) {
+      if (a.ny != 1) return -1;   // one workgroup per row block writes the materialised rows
+      hipLaunchKernelGGL((pw_fprop_kernel<T, KS, MI, 2>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    } else {
+      return -1;
+    }
+  } else if (a.in_scale != nullptr)
+    hipLaunchKernelGGL((pw_fprop_kernel<T, KS, MI, 1>), dim3((unsigned)nwg), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((pw_fprop_kernel<T, KS, MI, false>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((pw_fprop_kernel<T, KS, MI, 0>), dim3((unsigned)nwg), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -385,6 +466,8 @@ PDA_EXPORT int pda_conv_pw_fprop(int dtype, const void* x, const void* w, void* 
   a.stat_slots = stat_slots;
   a.stream_out = M * Co * 2 >= pda_stream_min_bytes();
   a.nch = a.nx = a.ny = 0;
+  a.mat_res = nullptr; a.mat_scale = nullptr; a.mat_shift = nullptr; a.mat_res_scale = nullptr; a.mat_out = nullptr;
+  a.mat_mask = nullptr;
 #define PDA_PW(T)                                          \
   switch (Ci) {                                            \
     case 64: return launch_pw<T, 1, 2>(a, stream);         \
@@ -395,4 +478,36 @@ PDA_EXPORT int pda_conv_pw_fprop(int dtype, const void* x, const void* w, void* 
   if (dtype == PDA_F16) { PDA_PW(f16) }
   PDA_PW(bf16)
 #undef PDA_PW
+}
+
+// The previous residual block's last pass and this block's first 1x1 convolution in one kernel (see PWArgs::mat_res):
+// out[M][Ci] = relu(y3 * scale + shift + res * res_scale) with its sign bits (mask: M * Ci / 8 bytes), and
+// y[M][Co] = out * w[Co][Ci]^T with the optional statistics of pda_conv_pw_fprop.  Ci = 256 or 512, Co <= 256, all
+// tensors dense [M][.].  <0: not covered.
+PDA_EXPORT int pda_conv_pw_fprop_mat(int dtype, const void* y3, const void* res, const float* scale, const float* shift,
+                                     const float* res_scale, void* out, unsigned char* mask, const void* w, void* y,
+                                     float* psum, float* psq, long long M, int Ci, int Co, int stat_slots,
+                                     hipStream_t stream) {
+  if (dtype != PDA_F16 && dtype != PDA_BF16) return -6;
+  if ((Ci != 256 && Ci != 512) || Co % 8 != 0 || Co <= 0 || Co > 256) return -1;
+  if (!y3 || !res || !scale || !shift || !res_scale || !out || !mask || !w || !y) return -11;
+  if ((((uintptr_t)y3 | (uintptr_t)res | (uintptr_t)out | (uintptr_t)mask | (uintptr_t)w | (uintptr_t)y |
+        (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)res_scale) & 15) != 0)
+    return -5;
+  if ((psum == nullptr) != (psq == nullptr)) return -11;
+  if (M <= 0) return 0;
+  const long long xb = M * Ci * 2;
+  if (M > 0x7fffffffLL || xb >= 0x7fffffffLL) return -10;
+  PWArgs a;
+  a.x = y3; a.w = w; a.y = y; a.in_scale = nullptr; a.in_shift = nullptr; a.psum = psum; a.psq = psq;
+  a.M = (int)M; a.K = Ci; a.N = Co; a.Ho = 1; a.Wo = 1;
+  a.sn = a.sh = a.sw = Ci;
+  a.x_bytes = xb;
+  a.lin = 1;
+  a.stat_slots = stat_slots;
+  a.stream_out = M * Co * 2 >= pda_stream_min_bytes();
+  a.nch = a.nx = a.ny = 0;
+  a.mat_res = res; a.mat_scale = scale; a.mat_shift = shift; a.mat_res_scale = res_scale; a.mat_out = out; a.mat_mask = mask;
+  if (dtype == PDA_F16) return Ci == 256 ? launch_pw<f16, 4, 2>(a, stream) : launch_pw<f16, 8, 1>(a, stream);
+  return Ci == 256 ? launch_pw<bf16, 4, 2>(a, stream) : launch_pw<bf16, 8, 1>(a, stream);
 }

@@ -54,6 +54,8 @@ def _init_fusion_state(block) -> None:
     block.defer_inner = (False, False)   # per inner hand-off: consumer normalises on load (set by the block)
     block._link_in = None        # per-forward: set by ResNet.features for the first conv
     block._link_out = None       # per-forward: read (and cleared) by ResNet.features
+    block.defer_out = False      # the next block's first conv can finish this block (see ResNet.fuse_relu_backward)
+    block._defer_out_now = False  # per-forward: set by ResNet.features when that next block really runs next
 
 
 def _links(block, n_inner: int):
@@ -64,7 +66,7 @@ def _links(block, n_inner: int):
     inner = tuple(BNBackwardLink(defer=block.defer_inner[i] and bool((_DEFER_MASK >> i) & 1)) if block.fuse_inner else None
                   for i in range(n_inner))
     pm = _premasked_out(block)
-    block._link_out = BNBackwardLink() if pm else None
+    block._link_out = BNBackwardLink(defer_out=block.defer_out and block._defer_out_now) if pm else None
     return in_link, inner, block._link_out, pm
 
 
@@ -200,10 +202,17 @@ class ResNet(tnn.Module):
         for b in blocks:
             b.premask_in = b.premasked_out = False
             b.fuse_inner = bool(enable)
+            b.defer_out = False
         if enable:
             for prev, nxt in zip(blocks[:-1], blocks[1:]):
                 prev.premasked_out = True
                 nxt.premask_in = True
+                # ... and where the next block starts with a fused 1x1 conv on 256 / 512 channels, that conv's kernel
+                # also runs the forward of this block's last pass (BatchNorm + shortcut + ReLU) on its operand rows
+                c1 = getattr(nxt, "conv1", None)
+                prev.defer_out = (isinstance(nxt, Bottleneck) and c1.kernel_size == (1, 1) and c1.stride == (1, 1)
+                                  and c1.in_channels in (256, 512) and c1.out_channels <= 256
+                                  and pnn.ConvBnAct.takes_fused_path(c1, torch.float16))
         return self
 
     def _make_layer(self, block, planes, blocks, stride=1):
@@ -249,11 +258,17 @@ class ResNet(tnn.Module):
         # block that consumes its output; the link is dropped from the modules right away - only the
         # autograd nodes of this forward keep it
         link = None
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for block in layer:
-                block._link_in = link
+        blocks = [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+        for i, block in enumerate(blocks):
+            block._link_in = link
+            # (only here is the consumer of the link known to run next; a hook on it would see the unfinished tensor)
+            block._defer_out_now = (i + 1 < len(blocks) and not blocks[i + 1]._forward_pre_hooks
+                                    and not blocks[i + 1]._forward_hooks)
+            try:
                 x = block(x)
-                link, block._link_out = block._link_out, None
+            finally:
+                block._defer_out_now = False
+            link, block._link_out = block._link_out, None
         return x
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:

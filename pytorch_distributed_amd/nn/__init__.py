@@ -168,6 +168,9 @@ class ConvBnAct(tnn.Module):
             # unfused modules (a bias, groups, or a channel count the MFMA kernels do not tile): the BatchNorm op masks its own ReLU gradient (dout_premasked needs nothing, a
             # link given to it stays empty), and the promise made by mask_dx / in_link is kept by an explicit
             # gradient mask on x
+            if in_link is not None and in_link.mat is not None:
+                from ..ops.fused import materialize_block_output
+                x = materialize_block_output(x, in_link)
             if in_link is not None and in_link.deferred:
                 from ..ops.fused import materialize_deferred
                 x = materialize_deferred(x, in_link)

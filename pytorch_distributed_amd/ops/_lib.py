@@ -62,6 +62,7 @@ _SIGS = {
     "pda_conv_pw_bm": [c_i],
     "pda_conv_pw_fprop": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i,
                           c_i, c_i, c_i, c_p],
+    "pda_conv_pw_fprop_mat": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p],
     "pda_conv_wgrad_ring": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_i, c_i, c_i, c_i,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_ll, c_p],
     "pda_krsc_to_crsk":[c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p],

@@ -221,6 +221,60 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
     return (y, psum, psq) if stats else y
 
 
+_ONES: dict = {}
+
+
+def _ones(n: int, device) -> torch.Tensor:
+    key = (n, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return t
+
+
+def pw_fprop_materialize(y3: torch.Tensor, res: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                         res_scale: Optional[torch.Tensor], w_krsc: torch.Tensor, stats: bool = False,
+                         stats_buf: Optional[torch.Tensor] = None):
+    """The last pass of a residual block and the next block's first 1x1 convolution in one kernel
+    (``csrc/kernels/pointwise_astat.hip``, MAT mode): ``out = relu(y3*scale + shift + res*res_scale)`` is formed in
+    fp32 on the convolution's operand rows, stored with its sign bits (as ``norm.apply(want_mask=True)`` would) and
+    multiplied into ``y = conv1x1(out, w)``.  ``y3`` / ``res``: ``[N,H,W,Ci]`` with ``Ci`` 256 or 512; ``w_krsc``:
+    ``[Co,1,1,Ci]``, ``Co <= 256``; ``scale`` / ``shift`` / ``res_scale``: fp32 ``[Ci]`` (``res_scale=None``: an
+    identity shortcut).  Returns ``(out, maskbits, y)`` or, with ``stats``, ``(out, maskbits, y, psum, psq)``;
+    ``None`` when the kernel does not cover the request."""
+    l = _lib.lib()
+    N, H, W, Ci = y3.shape
+    K = w_krsc.shape[0]
+    if (y3.element_size() != 2 or Ci not in (256, 512) or K > 256 or K % 8 or tuple(w_krsc.shape[1:]) != (1, 1, Ci)
+            or res.shape != y3.shape or res.dtype != y3.dtype or w_krsc.dtype != y3.dtype
+            or not (y3.is_contiguous() and res.is_contiguous() and w_krsc.is_contiguous())
+            or scale.dtype != torch.float32 or shift.dtype != torch.float32 or y3.numel() * 2 >= 2 ** 31 - 1):
+        return None
+    M = N * H * W
+    out = torch.empty_like(y3)
+    bits = torch.empty(y3.numel() // 8, device=y3.device, dtype=torch.uint8)
+    y = torch.empty((N, H, W, K), device=y3.device, dtype=y3.dtype)
+    psum = psq = None
+    slots = 0
+    if stats:
+        bm = l.pda_conv_pw_bm(Ci)
+        tiles_m = (M + bm - 1) // bm
+        if stats_buf is not None and tiles_m > stats_buf.shape[1]:
+            slots = stats_buf.shape[1]
+            psum, psq = stats_buf[0], stats_buf[1]
+        else:
+            part = torch.empty((2, tiles_m, K), device=y3.device, dtype=torch.float32)
+            psum, psq = part[0], part[1]
+    rs = _ones(Ci, y3.device) if res_scale is None else res_scale
+    rc = l.pda_conv_pw_fprop_mat(_lib.dt(y3), y3.data_ptr(), res.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                 rs.data_ptr(), out.data_ptr(), bits.data_ptr(), w_krsc.data_ptr(), y.data_ptr(),
+                                 _lib.ptr(psum), _lib.ptr(psq), M, Ci, K, slots, _lib.stream())
+    if rc < 0:
+        return None
+    _lib.check(rc, "pda_conv_pw_fprop_mat")
+    return (out, bits, y, psum, psq) if stats else (out, bits, y)
+
+
 def gemm_splitk(x: torch.Tensor, w: torch.Tensor, ksplit: int, cfg: int = 1) -> Optional[torch.Tensor]:
     """fp32 ``x[M, K] @ w[N, K]^T`` with the reduction spread over ``ksplit`` workgroups per output tile (float
     atomics into a zeroed result): for GEMMs whose ``ceil(M/128) * ceil(N/128)`` output tiles alone would leave

@@ -81,6 +81,7 @@ _FUSE_TAIL_BWD = int(os.environ.get("PDA_FUSE_TAIL_BWD", "3"))   # 1: 64->256 ta
 _FUSE_STEM_BWD = os.environ.get("PDA_FUSE_STEM_BWD", "1") == "1"
 _DEFER_SHORTCUT = os.environ.get("PDA_DEFER_SHORTCUT", "1") == "1"
 _COMPACT_SHORTCUT_GRAD = os.environ.get("PDA_COMPACT_SHORTCUT_GRAD", "1") == "1"
+_DEFER_BLOCK_OUT = os.environ.get("PDA_DEFER_BLOCK_OUT", "1") == "1"
 
 
 class BNBackwardLink:
@@ -103,16 +104,28 @@ class BNBackwardLink:
     nor read back.  A producer whose ReLU follows a residual add (its mask cannot be recomputed from ``y``) leaves
     the sign bits of its output in ``maskbits`` (one byte per 16-byte vector, written by the normalisation pass):
     the consumer's epilogue reads those instead of the activation itself.  Only a producer with a ReLU, no residual and batch statistics defers, and only for 16-bit
-    activations; a consumer that cannot fuse materialises the activation itself (``materialize_deferred``)."""
+    activations; a consumer that cannot fuse materialises the activation itself (``materialize_deferred``).
 
-    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine", "maskbits", "sums_buf")
+    With ``defer_out=True`` (the link between the LAST op of a residual block and the first 1x1 conv of the next
+    block, which also owns the next block's skip branch through ``passthrough``) the producer's whole last pass -
+    BatchNorm, shortcut add, ReLU, sign bits - moves into the consumer's forward kernel: the producer hands its raw
+    conv output on and leaves ``(scale, shift, residual, residual affine)`` in ``mat``; the consumer's pointwise
+    kernel forms the block output on its operand rows, stores it (it is the next skip branch, and what the
+    backward needs) with its sign bits, and multiplies it in (``conv.pw_fprop_materialize``).  The block output is
+    written once and not read back by that conv.  A consumer that cannot do this runs the producer's pass itself
+    (``materialize_block_output``); whoever takes the link must do one or the other."""
 
-    def __init__(self, defer: bool = False):
+    __slots__ = ("y", "scale", "shift", "relu", "remask", "sums", "defer", "deferred", "xaffine", "maskbits", "sums_buf",
+                 "defer_out", "mat")
+
+    def __init__(self, defer: bool = False, defer_out: bool = False):
         self.y = self.scale = self.shift = self.sums = self.xaffine = self.maskbits = self.sums_buf = None
         self.relu = True
         self.remask = False
         self.defer = defer
         self.deferred = False
+        self.defer_out = defer_out
+        self.mat = None
 
 
 class ShortcutLink:
@@ -152,6 +165,30 @@ class _AffineFn(torch.autograd.Function):
         return g, None, None
 
 
+class _BlockOutputFn(torch.autograd.Function):
+    """The block output ``relu(y * scale + shift + residual)`` of a producer that left its last pass to a consumer
+    which cannot run it inside its own kernel.  Towards autograd the producer's raw output already stands for the
+    block output, so the gradient passes through unchanged (the consumer masks it, as ``in_link`` demands)."""
+
+    @staticmethod
+    def forward(ctx, y, link):
+        scale, shift, res, raff = link.mat
+        link.mat = None
+        out, link.maskbits = Nm.apply(y.contiguous(), scale, shift, res, True, want_mask=True, res_affine=raff)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def materialize_block_output(x: torch.Tensor, in_link) -> torch.Tensor:
+    """``x`` itself, or the block output if ``in_link`` says the producing block left its last pass undone."""
+    if in_link is None or in_link.mat is None:
+        return x
+    return _BlockOutputFn.apply(x, in_link)
+
+
 def materialize_shortcut(residual, res_in):
     """``residual`` itself, or its normalised form if ``res_in`` says the producer skipped that pass."""
     if res_in is None or res_in.affine is None:
@@ -175,6 +212,21 @@ class _ConvBnActFn(torch.autograd.Function):
         train_stats = st.training or st.running_mean is None
         sbuf = cache.stats_buffer(K, x.device) if train_stats else None
         in_aff = None
+        r = None
+        if in_link is not None and in_link.mat is not None:
+            # x is the previous block's raw last conv output: finish that block on the way in (see BNBackwardLink)
+            m_scale, m_shift, m_res, m_raff = in_link.mat
+            in_link.mat = None
+            rm = None
+            if passthrough and (R, S) == (1, 1) and tuple(stride) == (1, 1) and tuple(pad) == (0, 0):
+                rm = C.pw_fprop_materialize(x, m_res, m_scale, m_shift if m_raff is None else m_shift + m_raff[1],
+                                            None if m_raff is None else m_raff[0], w_lp, stats=train_stats,
+                                            stats_buf=sbuf)
+            if rm is not None:
+                x, in_link.maskbits = rm[0], rm[1]
+                r = (rm[2], rm[3], rm[4]) if train_stats else rm[2]
+            else:
+                x, in_link.maskbits = Nm.apply(x, m_scale, m_shift, m_res, True, want_mask=True, res_affine=m_raff)
         if in_link is not None and in_link.deferred:
             # x is the producer's raw conv output: normalise it inside this conv's operand loads
             assert not passthrough, "a deferred activation has exactly one consumer"
@@ -183,7 +235,7 @@ class _ConvBnActFn(torch.autograd.Function):
             if r is None:
                 x = Nm.apply(x, in_link.scale, in_link.shift, None, True)
                 in_aff = None
-        if in_aff is None:
+        if in_aff is None and r is None:
             r = C.fprop_gpu(x, w_lp, stride, pad, stats=train_stats, stats_buf=sbuf)
         if r is None:
             raise RuntimeError(
@@ -217,6 +269,12 @@ class _ConvBnActFn(torch.autograd.Function):
             # a shortcut branch: the block's last op adds y * scale + shift itself (see ShortcutLink)
             out = y
             res_out.affine = (scale, shift)
+        elif (out_link is not None and out_link.defer_out and _DEFER_BLOCK_OUT and ctx.premasked and train_stats
+              and residual is not None and relu is True and _MASK_BITS and y.element_size() == 2 and K in (256, 512)
+              and not passthrough and not defer):
+            # the last op of a residual block whose successor finishes it inside its first conv (see BNBackwardLink)
+            out = y
+            out_link.mat = (scale, shift, residual, res_aff)
         elif defer:
             # the consumer normalises on load; autograd still sees this tensor as "the activation"
             out = y
@@ -258,8 +316,9 @@ class _ConvBnActFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, y if (train_stats or mean is not None) else None, mask_src, mean, invstd,
                               scale, shift, gamma)
         if passthrough:
-            # second output = alias of the input: whatever consumes it (the block's identity branch)
-            # sends its gradient back through THIS node, where the dgrad epilogue adds it for free
+            # second output = alias of the input (or the block output this op materialised from the previous block's
+            # raw one): whatever consumes it (the block's identity branch) sends its gradient back through THIS node,
+            # where the dgrad epilogue adds it for free
             return out, x.view_as(x)
         return out
 
@@ -478,6 +537,9 @@ def conv_bn_act(x, weight, gamma, beta, residual, stride, pad, relu, st: Nm.BNSt
     ``res_out`` / ``res_in`` / ``alias_link``: a :class:`ShortcutLink` shared by a shortcut branch's op (no
     activation), the op that takes its output as ``residual`` and the ``passthrough`` op whose alias output is the
     shortcut's input."""
+    if in_link is not None and in_link.mat is not None and (
+            not x.is_cuda or (not torch.is_grad_enabled() and not st.training and st.running_mean is not None)):
+        x = materialize_block_output(x, in_link)
     if res_in is not None and res_in.affine is not None and (not x.is_cuda or Nm.relu_cap(relu) is not None):
         residual = materialize_shortcut(residual, res_in)
         res_in = None
