@@ -949,9 +949,11 @@ def test_resnet_fwd_bwd_matches_reference(arch, dtype, hw, batch):
                                                  ("resnet50", torch.bfloat16, 64, 16)])
 def test_relu_backward_fusion_is_exact(arch, dtype, hw, batch, monkeypatch):
     """Block-output ReLU masks applied in the next block's dgrad epilogue == applied by the owning BatchNorm
-    backward: the same gradients, train and eval mode.  (Normalise-on-load, which rides on the same links, is
-    switched off here: it rounds the forward differently and has its own tests.)"""
+    backward: the same gradients, train and eval mode.  (Normalise-on-load and the block output finished by the next
+    block, which ride on the same links, are switched off here: they round the forward differently and have their own
+    tests.)"""
     monkeypatch.setattr(fused, "_DEFER_APPLY", False)
+    monkeypatch.setattr(fused, "_DEFER_BLOCK_OUT", False)
     torch.manual_seed(21)
     m = models.get_model(arch).to(DEV).set_compute_dtype(dtype)
     x = torch.randn(batch, 3, hw, hw, device=DEV)
