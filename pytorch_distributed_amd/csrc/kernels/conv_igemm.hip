@@ -1221,7 +1221,34 @@ template <int PITCH> __device__ __forceinline__ int trswz(int px) {
   else return 0;
 }
 
-template <typename T, int TM, int TN, int BKP, bool XF = false>
+// 16 bytes of a row at element alignment (RAG instantiations: channel counts that are no multiple of the 16-byte
+// vector, 58 / 116 / 232 in ShuffleNet).  Global memory takes the unaligned access in one instruction; `left`
+// < EPC marks the chunk that would run past the end of the tensor, fetched element by element with zero fill.
+template <typename T>
+__device__ __forceinline__ u32x4 rag_load(const T* __restrict__ p, int left) {
+  constexpr int EPC = 16 / sizeof(T);
+  u32x4 r = {0u, 0u, 0u, 0u};
+  if (left >= EPC) {
+    __builtin_memcpy(&r, p, 16);
+    return r;
+  }
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = i < left ? __builtin_bit_cast(unsigned, p[i]) : 0u;
+  } else {
+    unsigned short e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = i < left ? __builtin_bit_cast(unsigned short, p[i]) : (unsigned short)0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) r[d] = (unsigned)e[2 * d] | ((unsigned)e[2 * d + 1] << 16);
+  }
+  return r;
+}
+
+// RAG: 1x1 filters over channel counts that do not fill 16-byte vectors.  A chunk that straddles the end of a
+// pixel's channels carries the next pixel's first channels in its upper elements: those multiply into output
+// rows / columns >= Co / Ci, which are never stored - every dW element depends on its own channel pair only.
+template <typename T, int TM, int TN, int BKP, bool XF = false, bool RAG = false>
 __global__ void __launch_bounds__(256)
 wgrad_kernel(WgradArgs a) {
   constexpr int EPC = 16 / sizeof(T);
@@ -1302,8 +1329,11 @@ wgrad_kernel(WgradArgs a) {
       const int px = ypx + i * RPY;
       const int m = mstep + px;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (px < BKP && m < mend && yok_c)
-        v = *reinterpret_cast<const u32x4*>(DY + (long long)m * a.Co + k0 + ycc * EPC);
+      if (px < BKP && m < mend && yok_c) {
+        const T* __restrict__ p = DY + (long long)m * a.Co + k0 + ycc * EPC;
+        if constexpr (RAG) v = rag_load<T>(p, m == a.M - 1 ? a.Co - (k0 + ycc * EPC) : EPC);
+        else v = *reinterpret_cast<const u32x4*>(p);
+      }
       ry[i] = v;
     }
 #pragma unroll
@@ -1315,8 +1345,9 @@ wgrad_kernel(WgradArgs a) {
         const int hi = pho[i] * a.stride_h - a.pad_h + xr;
         const int wi = pwo[i] * a.stride_w - a.pad_w + xs;
         if ((unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi) {
-          v = *reinterpret_cast<const u32x4*>(X + (long long)pn[i] * a.sn + (long long)hi * a.sh +
-                                              (long long)wi * a.sw + xc);
+          const T* __restrict__ p = X + (long long)pn[i] * a.sn + (long long)hi * a.sh + (long long)wi * a.sw + xc;
+          if constexpr (RAG) v = rag_load<T>(p, m == a.M - 1 ? a.Ci - xc : EPC);
+          else v = *reinterpret_cast<const u32x4*>(p);
           if constexpr (XF) xlive |= 1u << i;
         }
       }
@@ -1858,7 +1889,7 @@ PDA_EXPORT int pda_conv_igemm_xf(int dtype, const void* x, const void* w, void* 
                          in_shift, stream);
 }
 
-template <typename T, int TM, int TN, int BKP>
+template <typename T, int TM, int TN, int BKP, bool RAG = false>
 static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
   const int tiles = ((a.Co + TM - 1) / TM) * ((a.Ktot + TN - 1) / TN);
   int nsplit = nsplit_hint;
@@ -1889,7 +1920,9 @@ static int launch_wgrad(WgradArgs a, int nsplit_hint, hipStream_t st) {
     nsplit = 1;
     a.pix_per_split = ((a.M + BKP - 1) / BKP) * BKP;
   }
-  if (a.in_scale != nullptr) {
+  if constexpr (RAG) {
+    hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP, false, true>), dim3(tiles, nsplit), dim3(256), 0, st, a);
+  } else if (a.in_scale != nullptr) {
     if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad_kernel<T, TM, TN, BKP, true>), dim3(tiles, nsplit), dim3(256), 0, st, a);
     else return -11;
   } else {
@@ -1991,6 +2024,35 @@ PDA_EXPORT int pda_conv_wgrad(int dtype, const void* dy, const void* x, float* d
                               float* workspace, long long workspace_bytes, hipStream_t stream) {
   return conv_wgrad_impl(dtype, dy, x, dw, N, Hi, Wi, Ci, sn, sh, sw, Ho, Wo, Co, R, S, stride_h, stride_w, pad_h,
                          pad_w, cfg, nsplit, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+// dW [Co][Ci] (fp32, zero-initialised or holding the gradient to accumulate into) += dY^T [Co][M] x X [M][Ci] for
+// ANY channel counts: the weight gradient of a pointwise convolution whose channels do not fill 16-byte vectors.
+// dy is dense [M][Co]; x has unit channel stride and a pixel pitch of ldx elements (a channel slice of a wider
+// tensor qualifies).  det != 0: run-to-run reproducible (one split per tile).
+PDA_EXPORT int pda_conv_wgrad_ragged(int dtype, const void* dy, const void* x, float* dw, long long M, int Ci, int Co,
+                                     long long ldx, int det, hipStream_t stream) {
+  if (M <= 0) return 0;
+  if (M > 0x7fffffffLL || Ci <= 0 || Co <= 0 || ldx < Ci) return -1;
+  const int es = dtype == PDA_F32 ? 4 : 2;
+  if ((((uintptr_t)x | (uintptr_t)dy) & (uintptr_t)(es - 1)) != 0) return -5;
+  WgradArgs a;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.slab = nullptr; a.slab_bytes = 0;
+  a.dy = dy; a.x = x; a.dw = dw; a.sn = 0; a.sh = 0; a.sw = ldx;
+  a.Hi = 1; a.Wi = (int)M; a.Ci = Ci; a.Ho = 1; a.Wo = (int)M; a.Co = Co; a.R = 1; a.S = 1;
+  a.stride_h = 1; a.stride_w = 1; a.pad_h = 0; a.pad_w = 0;
+  a.M = (int)M; a.Ktot = Ci; a.pix_per_split = 0; a.det = det;
+  a.r_lo = 0; a.r_hi = 0; a.s_lo = 0; a.s_hi = 0;
+  const bool small = Co <= 64 && Ci <= 64;
+  switch (dtype) {
+    case PDA_F16:
+      return small ? launch_wgrad<f16, 64, 64, 32, true>(a, 0, stream) : launch_wgrad<f16, 128, 128, 32, true>(a, 0, stream);
+    case PDA_BF16:
+      return small ? launch_wgrad<bf16, 64, 64, 32, true>(a, 0, stream) : launch_wgrad<bf16, 128, 128, 32, true>(a, 0, stream);
+    case PDA_F32:
+      return small ? launch_wgrad<float, 64, 64, 16, true>(a, 0, stream) : launch_wgrad<float, 128, 128, 16, true>(a, 0, stream);
+    default: return -6;
+  }
 }
 
 // Weight gradient against an input that is normalised on load (see pda_conv_igemm_xf): 16-bit types only.

@@ -48,6 +48,13 @@ __device__ __forceinline__ u32x4 fetch16(const T* __restrict__ row, int k, int k
   u32x4 r = {0u, 0u, 0u, 0u};
   if (!rowok || k >= kend) return r;
   if (vec && k + E <= kend) return *reinterpret_cast<const u32x4*>(row + k);
+  if (k + E <= kend) {
+    // a chunk inside a row whose pitch is not a multiple of 16 bytes (58, 116 channels ...): global memory
+    // takes a 16-byte access at element alignment (the HSA queues run in the unaligned access mode), so the
+    // chunk is still ONE load - only the chunk that straddles the end of the row goes element by element
+    __builtin_memcpy(&r, row + k, 16);
+    return r;
+  }
   if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = (k + i < kend) ? __builtin_bit_cast(unsigned, row[k + i]) : 0u;

@@ -32,6 +32,7 @@ _SIGS = {
     "pda_conv_dgrad_stat_rows": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
     "pda_conv_igemm": [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,
                        c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "pda_conv_wgrad_ragged": [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_ll, c_i, c_p],
     "pda_gemm_anyk": [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_ll, c_ll, c_ll, c_i, c_p],
     "pda_gemm_splitk": [c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "pda_conv_igemm_xf": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_ll, c_ll, c_ll,

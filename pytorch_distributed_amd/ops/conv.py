@@ -806,8 +806,8 @@ class _PointwiseGemmFn(torch.autograd.Function):
     """1x1 stride-1 convolution whose channel counts the implicit-GEMM fprop / dgrad kernels do not step
     through (16, 24, 58, 116, 144, 232 ... in the mobile architectures): forward and input gradient are plain
     ``[pixels, C] x [C, K]`` products on the any-shape MFMA GEMM of this package (:func:`gemm_nt`), the weight
-    gradient - a tiny ``[K, C]`` matrix reduced over millions of pixels - on the split-K wgrad kernel when the
-    channel counts fill 16-byte vectors, else on the same GEMM over the transposed operands."""
+    gradient - a tiny ``[K, C]`` matrix reduced over millions of pixels - on the split-K wgrad kernel (its ragged
+    instantiation, which reads rows at element alignment, when the channel counts do not fill 16-byte vectors)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -831,9 +831,16 @@ class _PointwiseGemmFn(torch.autograd.Function):
             vec = 16 // x.element_size()
             d = wgrad_gpu(dy, x.contiguous(), 1, 1, (1, 1), (0, 0)) if (K % vec == 0 and Cin % vec == 0) else None
             if d is None:
-                # dW [K, Cin] = dY^T [K, pixels] x X [pixels, Cin]: both operands transposed so that the reduction
-                # runs along rows (tiny outputs: the transposes are the cost of an odd channel count)
-                d = gemm_nt(dy.reshape(-1, K).t().contiguous(), x.reshape(-1, Cin).t().contiguous()).float()
+                # channel counts that do not fill 16-byte vectors (58, 116, 232 ...): the split-K wgrad kernel's
+                # ragged instantiation reads the rows at element alignment - no transposed copies of the operands
+                x2 = x.reshape(-1, Cin)
+                if x2.stride(1) != 1:
+                    x2 = x2.contiguous()
+                d = torch.zeros((K, Cin), device=dy.device, dtype=torch.float32)
+                _lib.check(_lib.lib().pda_conv_wgrad_ragged(_lib.dt(dy), dy.data_ptr(), x2.data_ptr(), d.data_ptr(),
+                                                            x2.shape[0], Cin, K, x2.stride(0),
+                                                            int(backends.deterministic), _lib.stream()),
+                           "pda_conv_wgrad_ragged")
             dw = d.reshape(K, Cin, 1, 1).to(wdtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(K, device=dy.device, dtype=torch.float32)

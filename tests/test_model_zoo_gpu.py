@@ -439,3 +439,28 @@ def test_odd_channel_pointwise_conv_runs_on_the_own_gemm(dtype, cin, cout, monke
     yr.backward(g.to(dtype).float())
     assert rel(x.grad, xr.grad.permute(0, 2, 3, 1)) < tol
     assert rel(w.grad, wr.grad) < tol and rel(bias.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout", [(58, 58), (116, 116), (232, 24), (13, 70)])
+def test_ragged_wgrad_on_channel_slices(dtype, cin, cout):
+    """Weight gradient of a pointwise conv over odd channel counts (conv_igemm.hip, ragged wgrad instantiation):
+    many pixels (several split-K workgroups), the input a channel SLICE of a wider tensor as in ShuffleNetV2's
+    channel split, against the fp32 product of the same 16-bit values."""
+    torch.manual_seed(cin * 7 + cout)
+    full = torch.randn(6, 37, 41, 2 * cin, device=DEV).to(dtype)
+    x = full[..., cin:].detach().requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, device=DEV) * 0.1).requires_grad_(True)
+    y = ops.conv2d(x, w, None, (1, 1), (0, 0))
+    g = torch.randn(y.shape, device=DEV).to(dtype)
+    y.backward(g)
+    ref_w = g.float().reshape(-1, cout).t() @ x.detach().float().reshape(-1, cin)
+    ref_x = g.float().reshape(-1, cout) @ w.detach().to(dtype).float().reshape(cout, cin)
+    ref_y = x.detach().float().reshape(-1, cin) @ w.detach().to(dtype).float().reshape(cout, cin).t()
+    tol = 1e-4 if dtype == torch.float32 else (2e-3 if dtype == torch.float16 else 1.5e-2)
+
+    def rel(a, r):
+        return float((a.detach().float().reshape(r.shape) - r).norm() / (r.norm() + 1e-30))
+    assert rel(y, ref_y) < tol
+    assert rel(w.grad, ref_w) < tol
+    assert rel(x.grad, ref_x) < tol
