@@ -82,6 +82,11 @@ __device__ __forceinline__ bf16x8 pw_affine_relu(bf16x8 v, bf16x8 sc, bf16x8 sf)
 
 // s_waitcnt immediate (gfx9 layout): vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
 constexpr int pw_waitcnt_vm(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (15 << 8); }
+// ... and lgkmcnt(0): the form in front of the ring barrier.  The compiler issues a step's last fragment reads ahead of
+// the barrier and consumes them behind it; the request that follows the barrier overwrites the very stage those reads
+// address, so they must have RETURNED (not merely been issued) before any wave passes the barrier.  (Without it about
+// one wave tile in two thousand multiplied a stale 8-row weight piece when a neighbouring workgroup kept the LDS busy.)
+constexpr int pw_waitcnt_vm_lds(int vm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | (0 << 8); }
 
 template <int OFF>
 __device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
@@ -297,11 +302,11 @@ pw_fprop_kernel(PWArgs a) {
       constexpr int e_static = ((1 % KS) == dsel) + ((2 % KS) == dsel) + ((3 % KS) == dsel);
       // (a workgroup on the ragged end of M skips whole store instructions: it waits for everything instead)
       const int e = ragged ? 0 : min(e_static, tile);
-      if (e == 0) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm((STAGES - 2) * PIECES));
-      else if (e == 1) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm((STAGES - 2) * PIECES + STORES));
-      else if (e == 2) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm((STAGES - 2) * PIECES + 2 * STORES));
-      else __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm((STAGES - 2) * PIECES + 3 * STORES));
-      __builtin_amdgcn_s_barrier();   // step s is complete, and everybody is done reading step s - 1
+      if (e == 0) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm_lds((STAGES - 2) * PIECES));
+      else if (e == 1) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm_lds((STAGES - 2) * PIECES + STORES));
+      else if (e == 2) __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm_lds((STAGES - 2) * PIECES + 2 * STORES));
+      else __builtin_amdgcn_s_waitcnt(pw_waitcnt_vm_lds((STAGES - 2) * PIECES + 3 * STORES));
+      __builtin_amdgcn_s_barrier();   // step s is complete, and everybody's reads of step s - 1 have returned
       issue((s + STAGES - 1) & (STAGES - 1));
       const unsigned char* sb = lds + (s & (STAGES - 1)) * STEP_BYTES;
       frag wf[2][NI];

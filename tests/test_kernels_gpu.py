@@ -525,6 +525,36 @@ def test_pointwise_kernel_finishes_the_previous_block(dtype, ci, co, m_shape, wi
                                   wk[..., :128].contiguous()) is None
 
 
+@pytest.mark.parametrize("mode", ["plain", "xf", "mat"])
+def test_pointwise_kernel_ring_is_race_free_at_full_occupancy(mode):
+    """The A-stationary pointwise kernel on 512 input channels at a size that fills the chip with two workgroups per
+    CU, statistics on, several launches: EVERY output element against the fp32 product.  (The compiler issues a ring
+    step's last fragment reads ahead of the step barrier; the wait in front of the barrier has to cover them, or the
+    next request overwrites the stage under a read that a busy LDS delayed - a few wave tiles per launch went wrong,
+    only at this occupancy and only with the statistics fold or the MAT prologue keeping the LDS busy.)"""
+    torch.manual_seed(31)
+    n, h, w_, ci, co = 64, 28, 28, 512, (256 if mode == "mat" else 512)
+    x = torch.randn(n, h, w_, ci, device=DEV).half()
+    wk = (torch.randn(co, 1, 1, ci, device=DEV) / ci ** 0.5).half()
+    sc, sf = torch.rand(ci, device=DEV) + 0.5, torch.randn(ci, device=DEV) * 0.3
+    res = torch.randn(n, h, w_, ci, device=DEV).half() if mode == "mat" else None
+    w32 = wk.float().reshape(co, ci).t()
+    if mode == "plain":
+        ref = x.float().reshape(-1, ci) @ w32
+    elif mode == "xf":
+        ref = torch.relu(x * sc.half() + sf.half()).float().reshape(-1, ci) @ w32
+    for rep in range(6):
+        if mode == "plain":
+            y = C.fprop_gpu(x, wk, (1, 1), (0, 0), stats=True, cfg=C._FPROP_PW_CFG)[0]
+        elif mode == "xf":
+            y = C.fprop_gpu(x, wk, (1, 1), (0, 0), stats=True, cfg=C._FPROP_PW_CFG, in_affine=(sc.half(), sf.half()))[0]
+        else:
+            out, _, y, _, _ = C.pw_fprop_materialize(x, res, sc, sf, None, wk, stats=True)
+            ref = out.float().reshape(-1, ci) @ w32
+        bad = (y.float().reshape(-1, co) - ref).abs() > 0.03
+        assert int(bad.sum()) == 0, (mode, rep, int(bad.sum()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_block_output_finished_by_the_next_block(dtype, monkeypatch):
     """A short bottleneck ResNet with each block's last pass (BatchNorm + shortcut + ReLU) run inside the next block's
@@ -1561,8 +1591,10 @@ def test_resnet50_bench_configuration_parity_224_b64():
         (la * 1024.0).backward()
         stock = {k: _cos(gr[k].grad, orc[k]) for k in names}
         assert ours["fc.weight"] > 0.99 and ours["fc.bias"] > 0.99, ours
+        # (a data race in the A-stationary pointwise kernel once showed here and nowhere else: 0.91 against 0.95 on
+        # layer4.2.conv3 - one wave tile in two thousand multiplied a stale piece of the weights)
         for k in names:
-            assert ours[k] > stock[k] - 0.1, (k, ours, stock)
+            assert ours[k] > stock[k] - 0.04, (k, ours, stock)
         opt.step()
         assert opt._amp_scaler_ref.skipped_steps() == 0
     finally:
