@@ -28,8 +28,9 @@ def main():
         ref.load_state_dict(m.state_dict())
         opt = FusedSGD(m.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
         m, opt = amp.initialize(m, opt, opt_level="O2", loss_scale=1024.0, verbosity=0)
-        x = torch.randn(64, 3, 224, 224, device=DEV)
-        t = torch.randint(0, 1000, (64,), device=DEV)
+        nb = int(os.environ.get("PROBE_BATCH", "64"))
+        x = torch.randn(nb, 3, 224, 224, device=DEV)
+        t = torch.randint(0, 1000, (nb,), device=DEV)
         for _ in range(2):
             opt.zero_grad(set_to_none=False)
             loss = ops.cross_entropy(m(x), t)
