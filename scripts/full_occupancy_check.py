@@ -1,0 +1,83 @@
+"""Every element of every conv kernel candidate at chip-filling sizes, several launches each, against fp32 autograd on
+the same 16-bit values.  Unit tests run small shapes; a race that needs two busy workgroups per CU only shows here.
+
+    python scripts/full_occupancy_check.py [--batch 128] [--reps 4]
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from pytorch_distributed_amd.ops import conv as C
+
+DEV = "cuda"
+LAYERS = [(56, 64, 64, 3, 1), (56, 64, 256, 1, 1), (56, 256, 64, 1, 1), (56, 128, 128, 3, 2), (56, 256, 512, 1, 2),
+          (28, 128, 128, 3, 1), (28, 128, 512, 1, 1), (28, 512, 128, 1, 1), (28, 256, 256, 3, 2), (14, 256, 256, 3, 1),
+          (14, 256, 1024, 1, 1), (14, 1024, 256, 1, 1), (14, 512, 512, 3, 2), (7, 512, 512, 3, 1), (7, 512, 2048, 1, 1),
+          (7, 2048, 512, 1, 1)]
+FCFGS = (1, 2, 9, 12, 5, 6, 7, 13, 33, 34)
+DCFGS = (1, 2, 9, 12, 5, 6, 7, 13)
+WCFGS = (1, 12, 65, 66, 68, 69, 70)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--batch", type=int, default=128)
+    p.add_argument("--reps", type=int, default=4)
+    a = p.parse_args()
+    total_bad = 0
+    for (hw, ci, co, k, s) in LAYERS:
+        torch.manual_seed(hw + ci + co)
+        pad = k // 2
+        x = torch.randn(a.batch, hw, hw, ci, device=DEV).half()
+        w = (torch.randn(co, k, k, ci, device=DEV) / (k * k * ci) ** 0.5).half()
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        wr = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride=s, padding=pad)
+        dy = torch.randn(yr.shape[0], yr.shape[2], yr.shape[3], co, device=DEV).half()
+        yr.backward(dy.float().permute(0, 3, 1, 2))
+        ref_y = yr.detach().permute(0, 2, 3, 1)
+        ref_dx = xr.grad.permute(0, 2, 3, 1)
+        ref_dw = wr.grad.permute(0, 2, 3, 1)
+        w_t = C.krsc_to_crsk(w, torch.float16)
+        tol_y = 0.02 * float(ref_y.abs().max())
+        tol_dx = 0.02 * float(ref_dx.abs().max())
+        tol_dw = 2e-3 * float(ref_dw.abs().max())
+        line = []
+        for kind, cfgs in (("fprop", FCFGS), ("dgrad", DCFGS), ("wgrad", WCFGS)):
+            for cfg in cfgs:
+                worst, nbad, ran = 0.0, 0, True
+                for rep in range(a.reps):
+                    if kind == "fprop":
+                        r = C.fprop_gpu(x, w, (s, s), (pad, pad), stats=True, cfg=cfg)
+                        if r is None:
+                            ran = False
+                            break
+                        d = (r[0].float() - ref_y).abs()
+                        tol = tol_y
+                    elif kind == "dgrad":
+                        r = C.dgrad_gpu(dy, w_t, (hw, hw), (s, s), (pad, pad), cfg=cfg)
+                        if r is None:
+                            ran = False
+                            break
+                        d = (r.float() - ref_dx).abs()
+                        tol = tol_dx
+                    else:
+                        r = C.wgrad_gpu(dy, x, k, k, (s, s), (pad, pad), cfg=cfg)
+                        if r is None:
+                            ran = False
+                            break
+                        d = (r - ref_dw).abs()
+                        tol = tol_dw
+                    worst = max(worst, float(d.max()) / tol)
+                    nbad += int((d > tol).sum())
+                if ran:
+                    line.append(f"{kind[0]}{cfg}:{'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})")
+                    total_bad += nbad
+        print(f"{hw:3d} {ci:5d}->{co:5d} k{k} s{s}: " + " ".join(line), flush=True)
+        del x, w, xr, wr, yr, dy, ref_y, ref_dx, ref_dw
+        torch.cuda.empty_cache()
+    print("TOTAL BAD ELEMENTS:", total_bad)
+    return 1 if total_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
