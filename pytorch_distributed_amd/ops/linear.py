@@ -100,8 +100,9 @@ class _LinearFn(torch.autograd.Function):
         w_lp = cache.get(weight, x.dtype)
         y = None
         tiles = ((B + 127) // 128) * ((N + 127) // 128)
-        if tiles * 2 <= _SPLITK_WORKGROUPS and K >= 2048 and _SPLITK_WORKGROUPS > 0:
-            # few output tiles under a deep reduction: split K over enough workgroups to fill the chip
+        if tiles * 2 <= _SPLITK_WORKGROUPS and K >= 2048 and _SPLITK_WORKGROUPS > 0 and not backends.deterministic:
+            # few output tiles under a deep reduction: split K over enough workgroups to fill the chip (float atomics
+            # into the fp32 accumulator: not when run-to-run reproducibility is asked for)
             ksplit = min(_SPLITK_WORKGROUPS // tiles, K // 256)
             acc = C.gemm_splitk(x, w_lp, ksplit)
             if acc is not None:

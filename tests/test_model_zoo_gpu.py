@@ -464,3 +464,37 @@ def test_ragged_wgrad_on_channel_slices(dtype, cin, cout):
     assert rel(y, ref_y) < tol
     assert rel(w.grad, ref_w) < tol
     assert rel(x.grad, ref_x) < tol
+
+
+@pytest.mark.parametrize("arch", ["resnet50", "resnext50_32x4d", "mobilenet_v2", "alexnet"])
+def test_deterministic_mode_is_bit_reproducible(arch):
+    """backends.deterministic: three forward + backward passes of a whole model on the same batch (same dropout masks)
+    give bit-identical logits and gradients at a size that fills the chip - any race between waves, and any float
+    atomic left on the path, shows as a difference.  (scripts/repro_check.py runs the same over every family.)"""
+    from pytorch_distributed_amd import backends
+    from pytorch_distributed_amd.ops import elementwise as E
+    old = backends.deterministic
+    backends.deterministic = True
+    try:
+        torch.manual_seed(0)
+        m = models.get_model(arch).to(DEV)
+        if hasattr(m, "set_compute_dtype"):
+            m.set_compute_dtype(torch.float16)
+        x = torch.randn(48, 3, 224, 224, device=DEV)
+        t = torch.randint(0, 1000, (48,), device=DEV)
+        state = {k: v.clone() for k, v in m.state_dict().items()}
+        runs = []
+        for _ in range(3):
+            m.load_state_dict(state)
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(7)
+            E._DROPOUT_CALLS = 0
+            logits = m(x)
+            (ops.cross_entropy(logits, t) * 128.0).backward()
+            runs.append((logits.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+        for r in runs[1:]:
+            assert torch.equal(r[0], runs[0][0])
+            for g0, g1 in zip(runs[0][1], r[1]):
+                assert torch.equal(g0, g1)
+    finally:
+        backends.deterministic = old
