@@ -75,8 +75,69 @@ def main():
         print(f"{hw:3d} {ci:5d}->{co:5d} k{k} s{s}: " + " ".join(line), flush=True)
         del x, w, xr, wr, yr, dy, ref_y, ref_dx, ref_dw
         torch.cuda.empty_cache()
+    total_bad += fused_kernels(a)
     print("TOTAL BAD ELEMENTS:", total_bad)
     return 1 if total_bad else 0
+
+
+def fused_kernels(a) -> int:
+    """The one-pass bottleneck-tail backward and the masked input gradient of the weight-stationary 3x3 kernel, every
+    element of dx, at the sizes they run at in ResNet-50."""
+    bad_total = 0
+    for (Ci, Co, hw) in ((64, 256, 56), (128, 512, 28)):
+        torch.manual_seed(Ci)
+        M = a.batch * hw * hw
+        dz = torch.randn(M, Co, device=DEV).half()
+        y3 = torch.randn(M, Co, device=DEV).half()
+        coef = torch.randn(5, Co, device=DEV) * torch.tensor([1.0, 0.1, 0.05, 1, 1], device=DEV).view(5, 1)
+        x2 = torch.randn(M, Ci, device=DEV).half()
+        scale = (torch.rand(Ci, device=DEV) + 0.5).half()
+        shift = (torch.rand(Ci, device=DEV) - 0.5).half()
+        w = (torch.randn(Co, 1, 1, Ci, device=DEV) / Ci ** 0.5).half()
+        wt = C.krsc_to_crsk(w, torch.float16)
+        dy3 = (coef[0] * dz.float() + coef[1] * y3.float() + coef[2]).half()
+        a2 = torch.relu(torch.addcmul(shift, x2, scale))
+        ref = (dy3.float() @ w.view(Co, Ci).float()) * (a2 > 0)
+        ref_dw = dy3.float().t() @ a2.float()
+        tol, tol_w = 0.02 * float(ref.abs().max()), 2e-3 * float(ref_dw.abs().max())
+        nbad, worst = 0, 0.0
+        for rep in range(a.reps):
+            dw = torch.zeros(Co, 1, 1, Ci, device=DEV)
+            dx, sums, dy = C.bottleneck_tail_bwd(dz, y3, coef, x2, (scale, shift), wt, dw if Ci == 64 else None)
+            d = (dx.float() - ref).abs()
+            nbad += int((d > tol).sum())
+            worst = max(worst, float(d.max()) / tol)
+            if Ci == 64:
+                dd = (dw.view(Co, Ci) - ref_dw).abs()
+                nbad += int((dd > tol_w).sum())
+                worst = max(worst, float(dd.max()) / tol_w)
+        print(f"tail backward {Ci:4d} -> {Co:4d} at {hw}x{hw}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
+        bad_total += nbad
+        del dz, y3, x2, ref, dy3, a2
+        torch.cuda.empty_cache()
+    # weight-stationary 3x3 (64 -> 64): masked dgrad with the BatchNorm sums, against fp32
+    torch.manual_seed(3)
+    n, hw = a.batch, 56
+    dy = torch.randn(n, hw, hw, 64, device=DEV).half()
+    w = (torch.randn(64, 3, 3, 64, device=DEV) / 24.0).half()
+    wt = C.krsc_to_crsk(w, torch.float16)
+    bn_in = torch.randn(n, hw, hw, 64, device=DEV).half()
+    sc, sf = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.3
+    ref = torch.nn.grad.conv2d_input((n, 64, hw, hw), w.float().permute(0, 3, 1, 2), dy.float().permute(0, 3, 1, 2),
+                                     stride=1, padding=1).permute(0, 2, 3, 1)
+    ref = ref * ((bn_in.float() * sc + sf) > 0)
+    tol = 0.02 * float(ref.abs().max())
+    nbad, worst = 0, 0.0
+    for rep in range(a.reps):
+        r = C.dgrad_gpu(dy, wt, (hw, hw), (1, 1), (1, 1), cfg=C._FPROP_C64_CFG, bn_input=bn_in, bn_scale=sc, bn_shift=sf,
+                        bn_sums=True)
+        d = (r[0].float() - ref).abs()
+        # (elements whose mask argument sits within rounding of zero may legitimately flip: count only real errors)
+        near = (bn_in.float() * sc + sf).abs() < 2e-3
+        nbad += int(((d > tol) & ~near).sum())
+        worst = max(worst, float(d[~near].max()) / tol)
+    print(f"weight-stationary 3x3 masked dgrad at {hw}x{hw}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
+    return bad_total + nbad
 
 
 if __name__ == "__main__":
