@@ -61,6 +61,7 @@ _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7, 13)   # 13: 256x128 ring on 2
 # 33: the A-stationary pointwise kernel (csrc/kernels/pointwise_astat.hip): unpadded 1x1, 64 / 128 / 256 / 512 input
 # channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
 _FPROP_PW_CFG = 33
+_FUSE_BIAS_RELU = os.environ.get("PDA_CONV_FUSE_BIAS_RELU", "1") == "1"   # plain convs: bias + ReLU in the GEMM epilogue
 _FPROP_C64_CFG = 34   # weight-stationary 3x3 on 64 -> 64 channels (csrc/kernels/conv3x3_c64.hip)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
 _DGRAD_EX_CFGS = (0, 1, 2, 3, 9, 10, 11, 5, 6)  # the fused-epilogue kernels have no 256x128 / 256x256 register tile
@@ -725,18 +726,23 @@ class _Conv2dFn(torch.autograd.Function):
         w_lp = cache.low_precision(weight, dtype)
         N, Hi, Wi, _ = x.shape
         Ho, Wo = out_size(Hi, R, stride[0], pad[0]), out_size(Wi, S, stride[1], pad[1])
-        y = fprop_gpu(x, w_lp, stride, pad)
+        # bias and ReLU ride in the GEMM epilogue (no pass of their own over the output); K a multiple of 4 keeps the
+        # epilogue's 16-byte bias loads aligned
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        fuse = _FUSE_BIAS_RELU and (bias is not None or relu) and K % 8 == 0
+        y = fprop_gpu(x, w_lp, stride, pad, relu=relu and fuse, bias=b32 if fuse else None)
         ctx.used_igemm = y is not None
         if y is None:
             y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=dtype)
-            direct_conv(0, x, w_lp, bias.float() if bias is not None else None, y,
-                        (N, Hi, Wi, C, Ho, Wo, K, R, S), stride, pad)
+            direct_conv(0, x, w_lp, b32, y, (N, Hi, Wi, C, Ho, Wo, K, R, S), stride, pad)
             if relu:
                 _lib.check(_lib.lib().pda_relu_fwd(_lib.dt(y), y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream()),
                            "pda_relu_fwd")
+        elif fuse:
+            pass
         elif bias is not None:
             l = _lib.lib()
-            _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), bias.float().data_ptr(), y.data_ptr(), y.numel(), K,
+            _lib.check(l.pda_bias_add(_lib.dt(y), y.data_ptr(), b32.data_ptr(), y.data_ptr(), y.numel(), K,
                                       int(relu), _lib.stream()), "pda_bias_add")
         elif relu:
             _lib.check(_lib.lib().pda_relu_fwd(_lib.dt(y), y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream()),
