@@ -23,7 +23,6 @@ from __future__ import annotations
 
 import contextlib
 import functools
-import warnings
 from typing import Optional, Union
 
 import torch

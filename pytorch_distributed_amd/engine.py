@@ -19,8 +19,8 @@ import torch
 
 from . import amp as _amp
 from . import models, ops, utils
-from .data import (DistributedSampler, make_loader, cifar10, synthetic_imagenet, SyntheticImages, DevicePrefetcher,
-                   CIFAR10_MEAN, CIFAR10_STD, IMAGENET_MEAN, IMAGENET_STD, imagenet, imagenet_available)
+from .data import (DistributedSampler, make_loader, cifar10, synthetic_imagenet, DevicePrefetcher,
+                   IMAGENET_MEAN, IMAGENET_STD, imagenet, imagenet_available)
 
 
 def build_parser(description: str = "PyTorch ImageNet Training", arch: str = "resnet18", epochs: int = 2,

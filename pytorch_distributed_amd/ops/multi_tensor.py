@@ -13,7 +13,6 @@ flatten/unflatten inside apex DDP (:178), and ``torch.optim.SGD.step``
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional, Sequence
 
 import torch

@@ -18,7 +18,7 @@ stays valid under hipGraph replay.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 from torch.optim import Optimizer

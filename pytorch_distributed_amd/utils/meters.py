@@ -6,7 +6,7 @@ accumulation helpers that avoid the reference's four host syncs per step."""
 from __future__ import annotations
 
 import time
-from typing import List, Optional
+from typing import List
 
 import torch
 
