@@ -58,7 +58,8 @@ def build_parser(description: str = "PyTorch ImageNet Training", arch: str = "re
     p.add_argument("--steps-per-epoch", default=0, type=int, help="cap iterations per epoch (0 = full)")
     p.add_argument("--jsonl", default="", type=str, help="per-step JSONL log (rank 0)")
     p.add_argument("--graph", action="store_true",
-                   help="single-GPU runs: record the training step into a hipGraph and replay it")
+                   help="GPU runs (one process, or one rank per GPU under DistributedDataParallel): record the training step "
+                        "into a hipGraph and replay it")
     p.add_argument("--cpu", action="store_true", help="force CPU + gloo (functional testing)")
     p.add_argument("--exact-eval", action="store_true", help="mask DistributedSampler padding in validation")
     return p
@@ -120,10 +121,13 @@ def train(loader, model, criterion, optimizer, epoch: int, device, args, zero_gr
     nb = len(loader) if not args.steps_per_epoch else min(len(loader), args.steps_per_epoch)
     progress = utils.ProgressMeter(nb, [batch_time, data_time, losses, top1, top5, thr], prefix=f"Epoch: [{epoch}]",
                                    rank0_only=True)
-    # --graph: single-process GPU runs replay the whole step as one hipGraph.  The recorded graph, its
+    # --graph: GPU runs replay the whole step as one hipGraph - a single process, or one rank per GPU under this
+    # package's DistributedDataParallel (its bucket pack, all-reduce and hand-over to the optimizer are stream work
+    # that records with the step; every rank records after the same three eager steps).  The recorded graph, its
     # static input buffers and the metric accumulator it writes to live on the optimizer across epochs.
-    use_graph = (getattr(args, "graph", False) and torch.device(device).type == "cuda" and _world() == 1
-                 and _takes_metrics(criterion))
+    graph_ddp = _graphable_ddp(model) if _world() > 1 else None
+    use_graph = (getattr(args, "graph", False) and torch.device(device).type == "cuda"
+                 and (_world() == 1 or graph_ddp is not None) and _takes_metrics(criterion))
     gstate = getattr(optimizer, "_pda_graph_state", None) if use_graph else None
     metrics = gstate["metrics"] if gstate is not None else utils.DeviceMetrics(device)
     metrics.reset()
@@ -164,7 +168,7 @@ def train(loader, model, criterion, optimizer, epoch: int, device, args, zero_gr
             if gstate["graph"] is None and gstate["eager"] >= 3:
                 # three ordinary steps have created every lazily built piece of state: record now
                 gx, gt = gstate["x"], gstate["t"]
-                gstate["graph"] = utils.GraphedStep(lambda: run_step(gx, gt), warmup=0, device=device)
+                gstate["graph"] = utils.GraphedStep(lambda: run_step(gx, gt), warmup=0, device=device, ddp=graph_ddp)
             if gstate["graph"] is not None:
                 gstate["graph"]()
             else:
@@ -189,6 +193,18 @@ def train(loader, model, criterion, optimizer, epoch: int, device, args, zero_gr
             if jsonl is not None and _rank() == 0:
                 jsonl.log(epoch=epoch, step=i, loss=l, acc1=a1, acc5=a5, images_per_sec=thr.val)
     return losses.avg, top1.avg
+
+
+def _graphable_ddp(model):
+    """The wrapper whose step can be recorded on several ranks: this package's DistributedDataParallel over a model
+    without SyncBatchNorm (its statistics all-reduce goes through the process group, outside the recorded streams)."""
+    from .nn import SyncBatchNorm
+    from .parallel import DistributedDataParallel
+    if not isinstance(model, DistributedDataParallel):
+        return None
+    if any(isinstance(m, SyncBatchNorm) for m in model.modules()):
+        return None
+    return model
 
 
 def _takes_metrics(criterion) -> bool:

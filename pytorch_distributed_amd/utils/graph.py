@@ -40,7 +40,8 @@ class GraphedStep:
                  enabled: bool = True, ddp=None):
         self._fn = fn
         if ddp is not None:
-            warmup = max(int(warmup), 2)
+            if getattr(ddp, "_rebuild_pending", False):
+                warmup = max(int(warmup), 2)   # the one-time bucket rebuild happens in the first backward passes
             if getattr(ddp, "_exposed_probe", None) is not None:
                 ddp.measure_exposed_comm(False)
         self._graph = None

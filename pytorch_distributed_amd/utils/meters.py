@@ -101,6 +101,8 @@ class DeviceMetrics:
         import torch.distributed as dist
         t = self.buf.clone()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if t.is_cuda and "nccl" not in str(dist.get_backend(group)):
+                t = t.cpu()     # a host-only group (gloo): four floats through its CPU path, not its device-tensor path
             dist.all_reduce(t, group=group)
         loss_sum, c1, c5, n = t.tolist()
         if reset:

@@ -172,3 +172,10 @@ def test_bench_supervisor_with_two_ranks_sharing_the_gpu():
     assert d["config"]["comm_backend"] == "p2p-twoshot" and d["config"]["wire_dtype"] == "float16"
     assert "rehearsal" in d["config"]["device"] and d["value"] > 0
     assert len(d["config"]["buckets"]) >= 1
+
+
+def test_engine_graph_replay_on_two_ranks():
+    """engine.train --graph under DistributedDataParallel on two ranks (sharing the GPU, peer-memory all-reduce):
+    the step is recorded after three eager steps on every rank and the epoch ends with the eager epoch's
+    parameters, bit for bit."""
+    _run_ranks(os.path.join(ROOT, "tests", "workers", "engine_graph_worker.py"), 2)

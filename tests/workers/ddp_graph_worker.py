@@ -36,6 +36,8 @@ def build(dev, rank, world, tag):
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(80, exit=True)     # a hang names its line
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -62,7 +64,14 @@ def main():
         l1 = s1()
     torch.cuda.synchronize()
     m2, o2, d2, c2 = build(dev, rank, world, "graph")
-    s2 = GraphedStep(make_step(d2, o2), warmup=WARM, ddp=d2)
+    if os.environ.get("PDA_TEST_WARM_ON_DEFAULT_STREAM") == "1":
+        # the way engine.train gets there: eager steps on the thread's own stream, then a recording without warm-up
+        st = make_step(d2, o2)
+        for _ in range(WARM):
+            st()
+        s2 = GraphedStep(st, warmup=0, ddp=d2)
+    else:
+        s2 = GraphedStep(make_step(d2, o2), warmup=WARM, ddp=d2)
     assert s2.captured
     for _ in range(STEPS):
         l2 = s2()
