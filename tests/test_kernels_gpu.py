@@ -1849,3 +1849,19 @@ def test_relu_mask_as_sign_bits(dtype, stride, cfg):
     b = C.dgrad_gpu(dy, wt, (H, W), (stride, stride), (1, 1), res=rx, cfg=cfg, mask=bits, mask_bits=True)
     assert a is not None and b is not None and torch.equal(a, b)
     assert (b[out <= 0] == 0).all()
+
+
+def test_every_conv_candidate_at_chip_filling_sizes(monkeypatch):
+    """scripts/full_occupancy_check.py as a test: every output element of every fprop / dgrad / wgrad tuner candidate at
+    ResNet-50's layer shapes (batch 64, two launches each), plus the fused tail backward and the weight-stationary
+    masked dgrad, against fp32 autograd - the sizes at which two busy workgroups share a CU, where the unit tests'
+    small shapes cannot see a race between waves."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "full_occupancy_check.py")
+    spec = importlib.util.spec_from_file_location("full_occupancy_check", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["full_occupancy_check.py", "--batch", "64", "--reps", "2"])
+    assert mod.main() == 0
