@@ -2,15 +2,17 @@
 ``datasets.CIFAR10(download=True)`` / ``datasets.MNIST(download=True)``
 (/root/reference/2.distributed.py:137, /root/reference/5.2.horovod_pytorch_mnist.py:135) become:
 
-* readers for the standard on-disk formats if the files are already there
-  (``cifar-10-batches-py`` is a python pickle, which this package refuses to execute, so CIFAR is
-  read from the binary version ``cifar-10-batches-bin``; MNIST from the idx-ubyte files), and
+* readers for the standard on-disk formats if the files are already there: CIFAR-10 from the binary version
+  ``cifar-10-batches-bin`` or from the ``cifar-10-batches-py`` directory that the reference's download leaves
+  behind (python pickles, read with an unpickler that admits numpy array reconstruction and nothing else, so a
+  crafted file cannot run code); MNIST from the idx-ubyte files, and
 * synthetic datasets of the same shapes (the benchmark configurations are synthetic).
 """
 from __future__ import annotations
 
 import gzip
 import os
+import pickle
 import struct
 from typing import Optional, Tuple
 
@@ -92,6 +94,42 @@ class CIFAR10Bin(Dataset):
         return x, int(self.labels[i])
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Unpickler for the CIFAR python batches: dicts of bytes / lists / numpy arrays.  Every global a numpy array
+    pickle refers to is listed here; anything else in the stream is refused instead of imported."""
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError(f"cifar-10-batches-py: refusing to load global {module}.{name}")
+        return super().find_class(module, name)
+
+
+class CIFAR10Py(CIFAR10Bin):
+    """CIFAR-10 python version (``cifar-10-batches-py/data_batch_[1-5]``, ``test_batch``): what
+    ``torchvision.datasets.CIFAR10(download=True)`` (/root/reference/2.distributed.py:137) leaves under ``root``."""
+
+    def __init__(self, root: str, train: bool = True, normalize: bool = True):
+        d = os.path.join(root, "cifar-10-batches-py")
+        files = [f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]
+        images, labels = [], []
+        for f in files:
+            with open(os.path.join(d, f), "rb") as fh:
+                entry = _ArraysOnlyUnpickler(fh, encoding="latin1").load()
+            images.append(np.asarray(entry["data"], dtype=np.uint8).reshape(-1, 3, 32, 32))
+            labels.extend(entry["labels"] if "labels" in entry else entry["fine_labels"])
+        self.images = torch.from_numpy(np.concatenate(images).copy())
+        self.labels = torch.tensor([int(v) for v in labels], dtype=torch.int64)
+        self.normalize = normalize
+        self.mean = torch.tensor(CIFAR10_MEAN).view(3, 1, 1)
+        self.std = torch.tensor(CIFAR10_STD).view(3, 1, 1)
+
+    @staticmethod
+    def available(root: str) -> bool:
+        return os.path.exists(os.path.join(root, "cifar-10-batches-py", "data_batch_1"))
+
+
 class MNISTIdx(Dataset):
     def __init__(self, root: str, train: bool = True, normalize: bool = True):
         pre = "train" if train else "t10k"
@@ -133,9 +171,13 @@ class MNISTIdx(Dataset):
 
 
 def cifar10(root: str, train: bool = True, synthetic: Optional[bool] = None):
-    """Real CIFAR-10 if its binary files are under ``root``, else the synthetic stand-in."""
-    if synthetic is False or (synthetic is None and root and CIFAR10Bin.available(root)):
+    """Real CIFAR-10 if its files (binary or python version) are under ``root``, else the synthetic stand-in."""
+    if root and CIFAR10Bin.available(root) and synthetic is not True:
         return CIFAR10Bin(root, train)
+    if root and CIFAR10Py.available(root) and synthetic is not True:
+        return CIFAR10Py(root, train)
+    if synthetic is False:
+        return CIFAR10Bin(root, train)      # asked for the real data: let the missing file be the error
     return synthetic_cifar10(train)
 
 

@@ -262,3 +262,40 @@ def test_cpu_binding_next_to_the_gpu(tmp_path, monkeypatch):
         assert real(0, sysfs=str(tmp_path)) is None
     finally:
         os.sched_setaffinity(0, set(allowed))
+
+
+def test_cifar10_python_batches_read_without_running_pickled_code(tmp_path):
+    """``cifar-10-batches-py`` (what the reference's ``datasets.CIFAR10(download=True)`` leaves on disk) is read through
+    an unpickler that admits numpy arrays only: a fixture written in the same layout loads, a file whose pickle
+    names any other callable is refused."""
+    import pickle
+    import numpy as np
+    from pytorch_distributed_amd.data import CIFAR10Py, cifar10
+    d = tmp_path / "cifar-10-batches-py"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    ref = {}
+    for name, n in [(f"data_batch_{i}", 20) for i in range(1, 6)] + [("test_batch", 12)]:
+        data = rng.integers(0, 256, size=(n, 3072), dtype=np.uint8)
+        labels = [int(v) for v in rng.integers(0, 10, size=n)]
+        ref[name] = (data, labels)
+        with open(d / name, "wb") as f:
+            pickle.dump({"batch_label": name, "labels": labels, "data": data, "filenames": ["x.png"] * n}, f, protocol=2)
+    assert CIFAR10Py.available(str(tmp_path))
+    tr, te = cifar10(str(tmp_path), True), cifar10(str(tmp_path), False)
+    assert isinstance(tr, CIFAR10Py) and len(tr) == 100 and len(te) == 12
+    x, y = tr[25]                                   # second file, sixth record
+    data, labels = ref["data_batch_2"]
+    assert y == labels[5]
+    raw = torch.from_numpy(data[5].reshape(3, 32, 32).copy()).float() / 255.0
+    mean, std = tr.mean, tr.std
+    assert torch.allclose(x, (raw - mean) / std)
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo should-never-run",))
+    with open(d / "data_batch_1", "wb") as f:
+        pickle.dump({"data": Evil(), "labels": []}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        CIFAR10Py(str(tmp_path), True)
