@@ -760,11 +760,25 @@ def worker(args) -> int:
     return 0
 
 
+def _keep_stdout_for_json() -> None:
+    """Native libraries write to file descriptor 1 as well (RCCL's version banner at communicator creation, gloo's
+    connection notes): send the descriptor to stderr and keep the real stdout for what this script prints - the JSON
+    line."""
+    try:
+        sys.stdout.flush()
+        real = os.dup(1)
+        os.dup2(2, 1)
+        sys.stdout = os.fdopen(real, "w", buffering=1)
+    except OSError:
+        pass
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return supervise(args, argv)
+    _keep_stdout_for_json()
     try:
         return worker(args)
     except Exception as e:  # noqa: BLE001 - a failed run must still say why, in the one place the driver reads
