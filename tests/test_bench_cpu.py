@@ -32,6 +32,9 @@ def test_bench_two_ranks_cpu(precision):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # ... and nothing else: what libraries write to file descriptor 1 (gloo's connection notes here, RCCL's banner on
+    # the GPU) is sent to stderr, stdout is the JSON line
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
