@@ -205,7 +205,12 @@ struct Philox {
 template <typename T>
 __global__ void __launch_bounds__(256)
 dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p, unsigned long long seed,
-               unsigned long long offset, int channel_mode, long long per_image, int C) {
+               unsigned long long offset, int channel_mode, long long per_image, int C,
+               const unsigned long long* __restrict__ replay) {
+  // `replay`: a device-resident counter added to the host's offset.  A step recorded into a hipGraph has the host
+  // offset baked in; the counter, advanced by the graph itself once per replay, gives every replay its own masks
+  // (and the backward of that replay the same ones as its forward).
+  if (replay != nullptr) offset += *replay;
   Philox rng(seed);
   const float keep_scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -329,8 +334,9 @@ PDA_EXPORT int pda_colsum(int dtype, const void* dy, float* out, long long M, in
   return pda_check_launch();
 }
 PDA_EXPORT int pda_dropout(int dtype, const void* x, void* y, long long n, float p, unsigned long long seed,
-                           unsigned long long offset, int channel_mode, long long per_image, int C, hipStream_t st) {
+                           unsigned long long offset, int channel_mode, long long per_image, int C,
+                           const unsigned long long* replay, hipStream_t st) {
   if (n == 0) return 0;
-  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n, p, seed, offset, channel_mode, per_image, C));
+  PDA_DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n, p, seed, offset, channel_mode, per_image, C, replay));
   return pda_check_launch();
 }

@@ -116,7 +116,7 @@ _SIGS = {
     "pda_peer_enable": [c_i, c_i],
     "pda_bias_add": [c_i, c_p, c_p, c_p, c_ll, c_i, c_i, c_p],
     "pda_colsum": [c_i, c_p, c_p, c_ll, c_i, c_i, c_p],
-    "pda_dropout": [c_i, c_p, c_p, c_ll, c_f, c_ull, c_ull, c_i, c_ll, c_i, c_p],
+    "pda_dropout": [c_i, c_p, c_p, c_ll, c_f, c_ull, c_ull, c_i, c_ll, c_i, c_p, c_p],
 }
 
 

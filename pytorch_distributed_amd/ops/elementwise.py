@@ -69,11 +69,34 @@ def relu6(x: torch.Tensor) -> torch.Tensor:
     return F.hardtanh(x, 0.0, 6.0) if not x.is_cuda else _ReluCapFn.apply(x, 6.0)
 
 
+_REPLAY: dict = {}          # per device: int64 counter added to every dropout offset on the device
+_REPLAY_STRIDE = 1 << 24    # (far above the number of dropout calls of one step)
+
+
+def _replay_counter(device: torch.device) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _REPLAY.get(idx)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=torch.device("cuda", idx))
+        _REPLAY[idx] = t
+    return t
+
+
+def advance_replay_counter(device) -> None:
+    """Called by ``utils.graph.GraphedStep`` as the last operation of a recorded step: the host-side dropout offsets
+    are constants of the recording, this device-side counter moves on with every replay - so the replays draw fresh
+    masks (a recorded VGG / MobileNet / MNIST-net step would otherwise drop the same units every iteration)."""
+    device = torch.device(device)
+    if device.type == "cuda" and (device.index if device.index is not None else torch.cuda.current_device()) in _REPLAY:
+        _replay_counter(device).add_(_REPLAY_STRIDE)
+
+
 def _launch_dropout(x, p, seed, offset, channel_mode, per_image, Cc):
     l = _lib.lib()
     y = torch.empty_like(x)
     _lib.check(l.pda_dropout(_lib.dt(x), x.data_ptr(), y.data_ptr(), x.numel(), float(p), seed, offset,
-                             int(channel_mode), per_image, Cc, _lib.stream()), "pda_dropout")
+                             int(channel_mode), per_image, Cc, _replay_counter(x.device).data_ptr(), _lib.stream()),
+               "pda_dropout")
     return y
 
 

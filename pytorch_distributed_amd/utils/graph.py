@@ -64,6 +64,10 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=self._stream):
             self._out = fn()
+            # dropout masks: the host-side Philox offsets are constants of the recording; the device-side counter the
+            # kernels add to them moves on here, once per replay
+            from ..ops.elementwise import advance_replay_counter
+            advance_replay_counter(dev)
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._graph = graph
 

@@ -1865,3 +1865,34 @@ def test_every_conv_candidate_at_chip_filling_sizes(monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", ["full_occupancy_check.py", "--batch", "64", "--reps", "2"])
     assert mod.main() == 0
+
+
+def test_dropout_draws_fresh_masks_on_every_graph_replay():
+    """A step with dropout recorded into a hipGraph: the host-side Philox offset is a constant of the recording, the
+    device-side counter advanced by the graph gives every replay its own mask - and the backward of a replay the
+    mask of its forward."""
+    from pytorch_distributed_amd.utils.graph import GraphedStep
+    x = torch.ones(1 << 16, device=DEV, requires_grad=True)
+    out = {}
+
+    def step():
+        x.grad = None
+        y = ops.dropout(x, 0.5, True)
+        y.sum().backward()
+        out["y"], out["g"] = y.detach(), x.grad
+        return y.detach()
+
+    g = GraphedStep(step, warmup=1, device=torch.device(DEV))
+    assert g.captured
+    masks = []
+    for _ in range(4):
+        g()
+        torch.cuda.synchronize()
+        y, gr = out["y"].clone(), out["g"].clone()
+        assert torch.equal(y > 0, gr > 0)                 # backward regenerates the forward's mask
+        assert 0.45 < float((y > 0).float().mean()) < 0.55
+        masks.append(y > 0)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert not torch.equal(masks[i], masks[j])    # a fresh mask per replay
+            assert 0.4 < float((masks[i] == masks[j]).float().mean()) < 0.6    # ... independent of the others
