@@ -86,6 +86,7 @@ def main():
         del x, w, xr, wr, yr, dy, ref_y, ref_dx, ref_dw
         torch.cuda.empty_cache()
     total_bad += fused_kernels(a)
+    total_bad += dgrad_epilogues(a)
     print("TOTAL BAD ELEMENTS:", total_bad)
     return 1 if total_bad else 0
 
@@ -156,6 +157,52 @@ def fused_kernels(a) -> int:
         worst = max(worst, float(d[~near].max()) / tol)
     print(f"weight-stationary 3x3 masked dgrad at {hw}x{hw}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
     return bad_total + nbad
+
+
+def dgrad_epilogues(a) -> int:
+    """The input-gradient kernels with the fused epilogue (residual gradient added, the producer's ReLU mask recomputed
+    from its conv output, the two BatchNorm-backward sums): dx against fp32 and bit for bit across launches."""
+    bad_total = 0
+    for (hw, ci, co, k) in ((56, 256, 64, 1), (28, 128, 128, 3), (14, 256, 256, 3), (14, 1024, 256, 1)):
+        torch.manual_seed(hw + ci)
+        pad = k // 2
+        n = a.batch
+        dy = torch.randn(n, hw, hw, co, device=DEV).half()
+        w = (torch.randn(co, k, k, ci, device=DEV) / (k * k * ci) ** 0.5).half()
+        wt = C.krsc_to_crsk(w, torch.float16)
+        res = torch.randn(n, hw, hw, ci, device=DEV).half()
+        bn_in = torch.randn(n, hw, hw, ci, device=DEV).half()
+        sc, sf = torch.rand(ci, device=DEV) + 0.5, torch.randn(ci, device=DEV) * 0.3
+        ref = torch.nn.grad.conv2d_input((n, ci, hw, hw), w.float().permute(0, 3, 1, 2), dy.float().permute(0, 3, 1, 2),
+                                         stride=1, padding=pad).permute(0, 2, 3, 1)
+        arg = bn_in.float() * sc + sf
+        ref = (ref + res.float()) * (arg > 0)
+        near = arg.abs() < 2e-3
+        tol = 0.02 * float(ref.abs().max())
+        line = []
+        for cfg in (1, 2, 3, 9, 10, 11, 5, 6):
+            nbad, worst, first, ran = 0, 0.0, None, True
+            for rep in range(a.reps):
+                r = C.dgrad_gpu(dy, wt, (hw, hw), (1, 1), (pad, pad), res=res, cfg=cfg, bn_input=bn_in, bn_scale=sc,
+                                bn_shift=sf, bn_sums=True)
+                if r is None:
+                    ran = False
+                    break
+                dx = r[0]
+                d = (dx.float() - ref).abs()
+                nbad += int(((d > tol) & ~near).sum())
+                worst = max(worst, float(d[~near].max()) / tol)
+                if first is None:
+                    first = dx
+                else:
+                    nbad += int((first != dx).sum())
+            if ran:
+                line.append(f"e{cfg}:{'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})")
+                bad_total += nbad
+        print(f"dgrad + epilogue {hw:3d} {co:5d}->{ci:5d} k{k}: " + " ".join(line), flush=True)
+        del dy, w, res, bn_in, ref, arg, near
+        torch.cuda.empty_cache()
+    return bad_total
 
 
 if __name__ == "__main__":
