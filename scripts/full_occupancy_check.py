@@ -87,6 +87,7 @@ def main():
         torch.cuda.empty_cache()
     total_bad += fused_kernels(a)
     total_bad += dgrad_epilogues(a)
+    total_bad += grouped_convs(a)
     print("TOTAL BAD ELEMENTS:", total_bad)
     return 1 if total_bad else 0
 
@@ -201,6 +202,44 @@ def dgrad_epilogues(a) -> int:
                 bad_total += nbad
         print(f"dgrad + epilogue {hw:3d} {co:5d}->{ci:5d} k{k}: " + " ".join(line), flush=True)
         del dy, w, res, bn_in, ref, arg, near
+        torch.cuda.empty_cache()
+    return bad_total
+
+
+def grouped_convs(a) -> int:
+    """ResNeXt's grouped 3x3 layers (32 groups) on the chunk kernels: forward, input and weight gradient through the
+    autograd op, against fp32; forward and input gradient bit for bit across launches."""
+    from pytorch_distributed_amd import ops
+    bad_total = 0
+    for (hw, c, s_) in ((56, 128, 1), (56, 256, 2), (28, 256, 1), (14, 512, 1), (7, 1024, 1)):
+        torch.manual_seed(hw + c)
+        n, g = a.batch, 32
+        x = torch.randn(n, hw, hw, c, device=DEV).half()
+        w = (torch.randn(c, c // g, 3, 3, device=DEV) / (9 * c // g) ** 0.5)
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        wr = w.half().float().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride=s_, padding=1, groups=g)
+        gy = torch.randn(yr.shape[0], yr.shape[2], yr.shape[3], c, device=DEV).half()
+        yr.backward(gy.float().permute(0, 3, 1, 2))
+        ref_y, ref_dx, ref_dw = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad
+        tols = (0.02 * float(ref_y.abs().max()), 0.02 * float(ref_dx.abs().max()), 3e-3 * float(ref_dw.abs().max()))
+        nbad, worst, first = 0, 0.0, None
+        for rep in range(a.reps):
+            xg = x.clone().requires_grad_(True)
+            wg = w.clone().requires_grad_(True)
+            y = ops.conv2d(xg, wg, None, (s_, s_), (1, 1), groups=g)
+            y.backward(gy)
+            for got, ref, tol in ((y.detach(), ref_y, tols[0]), (xg.grad, ref_dx, tols[1]), (wg.grad, ref_dw, tols[2])):
+                d = (got.float() - ref).abs()
+                nbad += int((d > tol).sum())
+                worst = max(worst, float(d.max()) / tol)
+            if first is None:
+                first = (y.detach().clone(), xg.grad.clone())
+            else:
+                nbad += int((first[0] != y.detach()).sum()) + int((first[1] != xg.grad).sum())
+        print(f"grouped 3x3 {hw:3d} {c:5d} g{g} s{s_}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
+        bad_total += nbad
+        del x, xr, yr, gy, ref_y, ref_dx
         torch.cuda.empty_cache()
     return bad_total
 
