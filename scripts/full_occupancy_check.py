@@ -88,6 +88,7 @@ def main():
     total_bad += fused_kernels(a)
     total_bad += dgrad_epilogues(a)
     total_bad += grouped_convs(a)
+    total_bad += stem_backward(a)
     print("TOTAL BAD ELEMENTS:", total_bad)
     return 1 if total_bad else 0
 
@@ -242,6 +243,54 @@ def grouped_convs(a) -> int:
         del x, xr, yr, gy, ref_y, ref_dx
         torch.cuda.empty_cache()
     return bad_total
+
+
+def stem_backward(a) -> int:
+    """The stem's one-pass backward (BatchNorm backward apply + 7x7 weight gradient) at 224x224 against the separate
+    kernels: dW of the conv and the BatchNorm gradients, several launches (float atomics on dW: equal to rounding)."""
+    from pytorch_distributed_amd import nn as pnn, ops
+    from pytorch_distributed_amd.ops import fused
+    torch.manual_seed(9)
+    n = a.batch
+    conv = pnn.Conv2d(3, 64, 7, 2, 3, bias=False).to(DEV)
+    bn = pnn.BatchNorm2d(64).to(DEV)
+    img = torch.randn(n, 3, 224, 224, device=DEV)
+    g = None
+
+    def run(fuse_on):
+        nonlocal g
+        old = fused._FUSE_STEM_BWD
+        fused._FUSE_STEM_BWD = fuse_on
+        try:
+            for p in (conv.weight, bn.weight, bn.bias):
+                p.grad = None
+            y = ops.stem_conv_bn_relu_pool(img, conv.weight, bn.weight, bn.bias, conv.stride, conv.padding, bn.state(),
+                                           torch.float16, pool=(3, 2, 1))
+            if g is None:
+                g = torch.randn_like(y)
+            y.backward(g)
+            return [p.grad.float().clone() for p in (conv.weight, bn.weight, bn.bias)]
+        finally:
+            fused._FUSE_STEM_BWD = old
+
+    ref = run(False)
+    nbad, worst = 0, 0.0
+    calls = []
+    real = C.stem_bwd_fused
+    C.stem_bwd_fused = lambda *args, **kw: (calls.append(1), real(*args, **kw))[1]
+    for rep in range(a.reps):
+        got = run(True)
+        for r_, g_ in zip(ref, got):
+            tol = 3e-3 * float(r_.abs().max())
+            d = (r_ - g_).abs()
+            nbad += int((d > tol).sum())
+            worst = max(worst, float(d.max()) / tol)
+    C.stem_bwd_fused = real
+    if len(calls) != a.reps:
+        print("stem backward: the one-pass kernel did not run")
+        return 1
+    print(f"stem backward in one pass at 224x224: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
+    return nbad
 
 
 if __name__ == "__main__":
