@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench modes added this round: hvd engine (+SyncBN, +eval), selftest, bucket sweep, graphed DDP; shared-GPU rehearsals
+# bench modes beyond the default: hvd engine (+SyncBN, +eval), selftest, bucket sweep, graphed DDP; shared-GPU rehearsals
 mkdir -p gpurun_out
 export PYTHONPATH=$GRAFT_REPO_ROOT HSA_ENABLE_IPC_MODE_LEGACY=0
 S=gpurun_out/r3_modes_summary.txt; : > $S

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC pass over the 14x14 256->256 3x3 layer (batch 256) with this round's kernels: fprop ring tiles after the
+# PMC pass over the 14x14 256->256 3x3 layer (batch 256) with the ring kernels: fprop ring tiles after the
 # builtin-wait loop, the ring wgrad, and the A-stationary pointwise kernel on the 14x14 256->1024 layer
 set -o pipefail
 mkdir -p gpurun_out

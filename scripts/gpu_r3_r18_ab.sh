@@ -1,5 +1,5 @@
 #!/bin/bash
-# ResNet-18 on 32x32 input, batch 800 (the launch-bound workload): A/B of this round's fusions, eager and graph
+# ResNet-18 on 32x32 input, batch 800 (the launch-bound workload): A/B of the shortcut / block-output fusions, eager and graph
 set -o pipefail
 mkdir -p gpurun_out
 run() { # label, env..., -- args
