@@ -212,9 +212,13 @@ def grouped_convs(a) -> int:
     autograd op, against fp32; forward and input gradient bit for bit across launches."""
     from pytorch_distributed_amd import ops
     bad_total = 0
-    for (hw, c, s_) in ((56, 128, 1), (56, 256, 2), (28, 256, 1), (14, 512, 1), (7, 1024, 1)):
+    # (c, groups): ResNeXt's 32 groups, then depthwise layers of MobileNetV2 / ShuffleNetV2 (58 and 116 channels: the
+    # 4-byte-per-lane instantiations)
+    for (hw, c, s_, g) in ((56, 128, 1, 32), (56, 256, 2, 32), (28, 256, 1, 32), (14, 512, 1, 32), (7, 1024, 1, 32),
+                           (112, 32, 1, 32), (112, 96, 2, 96), (56, 144, 1, 144), (28, 58, 1, 58), (14, 116, 2, 116),
+                           (14, 576, 1, 576)):
         torch.manual_seed(hw + c)
-        n, g = a.batch, 32
+        n = a.batch
         x = torch.randn(n, hw, hw, c, device=DEV).half()
         w = (torch.randn(c, c // g, 3, 3, device=DEV) / (9 * c // g) ** 0.5)
         xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
@@ -238,7 +242,7 @@ def grouped_convs(a) -> int:
                 first = (y.detach().clone(), xg.grad.clone())
             else:
                 nbad += int((first[0] != y.detach()).sum()) + int((first[1] != xg.grad).sum())
-        print(f"grouped 3x3 {hw:3d} {c:5d} g{g} s{s_}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
+        print(f"{'depthwise' if g == c else 'grouped  '} 3x3 {hw:3d} {c:5d} g{g} s{s_}: {'ok' if nbad == 0 else 'BAD ' + str(nbad)}({worst:.2f})", flush=True)
         bad_total += nbad
         del x, xr, yr, gy, ref_y, ref_dx
         torch.cuda.empty_cache()
