@@ -131,3 +131,18 @@ def test_image_directory_pipeline_on_the_gpu(tmp_path):
                "-a", "resnet50", "-b", "4", "--epochs", "1", "--num-classes", "2", "-j", "2", "-p", "1",
                "--precision", "fp16", "--opt-level", "O2"], tmp_path)
     assert txt.count(" * Acc@1") == 1 and "Epoch: [0][1/2]" in txt
+
+
+def test_bench_with_stock_comparator_in_a_child_process(tmp_path):
+    """`python bench.py` with the comparator on (a tiny configuration): stdout is ONE JSON line carrying the native
+    number and `vs_stock`, measured by a child process whose failure could not have cost the native result."""
+    import json
+    out = run([sys.executable, os.path.join(ROOT, "bench.py"), "--arch", "resnet18", "--image-size", "32",
+               "--batch-size", "64", "--num-classes", "10", "--steps", "3", "--warmup", "2", "--compare-stock"], tmp_path)
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 1
+    assert isinstance(d["config"]["stock_images_per_sec"], float) and d["config"]["stock_images_per_sec"] > 0
+    assert d["vs_stock"] == pytest.approx(d["value"] / d["config"]["stock_images_per_sec"], rel=1e-2)
+    assert "child process" in d["config"]["stock_comparator"]
