@@ -172,6 +172,13 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
                                    in_affine is not None), cands,
                          lambda c: fprop_gpu(x, w_krsc, stride, pad, res, relu, stats, c or 1 << 30, geom, None, bias,
                                              in_affine))
+    if cfg == 0 and not backends.benchmark and geom is None:
+        # without the tuner: the specialised kernels where they win on every measured layer (the weight-stationary
+        # 3x3 on 64 -> 64 channels; the A-stationary pointwise kernel up to 256 input channels)
+        if c64_ok:
+            cfg = _FPROP_C64_CFG
+        elif pw_ok and Ci <= 256:
+            cfg = _FPROP_PW_CFG
     cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
     if cfg == _FPROP_C64_CFG:
         y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
@@ -332,6 +339,8 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
                          (_DGRAD_EX_CFGS if extras else _FPROP_CFGS) + ((_FPROP_C64_CFG,) if c64_ok else ()),
                          lambda c: dgrad_gpu(dy, w_crsk, in_hw, stride, pad, res, c or 1 << 30, mask, bn_input, bn_scale,
                                              bn_shift, bn_sums, mask_bits, None, res_s2))
+    if cfg == 0 and not backends.benchmark and c64_ok:
+        cfg = _FPROP_C64_CFG        # without the tuner: the weight-stationary kernel wins on this layer type
     cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
     if cfg == _FPROP_C64_CFG:
