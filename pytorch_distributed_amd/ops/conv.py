@@ -454,6 +454,15 @@ def wgrad_gpu(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, stride, pad, cf
                              in_affine is None or (tuple(pad) == (0, 0) and R == 1 and S == 1)) else ()),
                          lambda c: wgrad_gpu(dy, x, R, S, stride, pad, c or 1 << 30, 0, geom, None, workspace,
                                              in_affine))
+    if (cfg == 0 and nsplit == 0 and not backends.benchmark and geom is None and dy.element_size() == 2
+            and (in_affine is None or (tuple(pad) == (0, 0) and R == 1 and S == 1))):
+        # without the tuner: the LDS-DMA ring kernel, 256x128 tiles for the deep reductions over small images and
+        # 128x128 otherwise (the best static choice over ResNet-50's layers: 6.6 against 7.95 ms per step for the
+        # register-staged heuristic, 6.05 for the per-layer best; scripts/wgrad_cfg_totals.py)
+        deep = Ho * Wo <= 196 and (R * S > 1 or (K >= 512 and R * S * Ci >= 1024))
+        r = wgrad_gpu(dy, x, R, S, stride, pad, 68 if deep else 65, 0, geom, out, workspace, in_affine)
+        if r is not None:
+            return r
     cfg &= (1 << 30) - 1
     if backends.deterministic:
         cfg |= 32
