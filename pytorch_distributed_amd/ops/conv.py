@@ -179,6 +179,12 @@ def fprop_gpu(x: torch.Tensor, w_krsc: torch.Tensor, stride: Tuple[int, int], pa
             cfg = _FPROP_C64_CFG
         elif pw_ok and Ci <= 256:
             cfg = _FPROP_PW_CFG
+        elif x.element_size() == 2 and K >= 128 and res is None and in_affine is None:
+            # ... and the 256x128 LDS-DMA ring tile on 2x2 waves from 128 output channels up: 6.46 against 6.97 ms per
+            # step over ResNet-50's layers for the register-staged heuristic (scripts/fprop_dgrad_cfg_totals.py)
+            r = fprop_gpu(x, w_krsc, stride, pad, None, relu, stats, 13, None, stats_buf, bias, None)
+            if r is not None:
+                return r
     cfg &= (1 << 30) - 1   # (1 << 30: "heuristic, and do not tune" - the tuner's own call for candidate 0)
     if cfg == _FPROP_C64_CFG:
         y = torch.empty((N, Ho, Wo, K), device=x.device, dtype=x.dtype)
@@ -341,6 +347,11 @@ def dgrad_gpu(dy: torch.Tensor, w_crsk: torch.Tensor, in_hw: Tuple[int, int], st
                                              bn_shift, bn_sums, mask_bits, None, res_s2))
     if cfg == 0 and not backends.benchmark and c64_ok:
         cfg = _FPROP_C64_CFG        # without the tuner: the weight-stationary kernel wins on this layer type
+    elif (cfg == 0 and not backends.benchmark and dy.element_size() == 2 and C >= 128 and res is None and mask is None
+          and bn_input is None and not res_s2):
+        r = dgrad_gpu(dy, w_crsk, in_hw, stride, pad, cfg=13)      # ... and the 256x128 ring tile for plain input gradients
+        if r is not None:
+            return r
     cfg &= (1 << 30) - 1
     dx = torch.empty((N, Hi, Wi, C), device=dy.device, dtype=dy.dtype)
     if cfg == _FPROP_C64_CFG:
