@@ -64,8 +64,9 @@ def main():
     p.add_argument("--graph", action="store_true", help="replay the training step as a hipGraph")
     p.add_argument("--keep-garbage", action="store_true",
                    help="diagnostic: do not collect the previous model before the next one is measured")
+    p.add_argument("--no-autotune", action="store_true", help="static kernel choices instead of the per-shape tuner")
     a = p.parse_args()
-    backends.benchmark = True
+    backends.benchmark = not a.no_autotune
     for arch in a.archs.split(","):
         ips = run(arch, a.batch, a.steps, a.warmup, a.size, a.graph)
         line = f"{arch:18s} batch {a.batch:4d}  {a.size}x{a.size}  fp16 O2{' graph' if a.graph else ''}  {ips:10.1f} img/s  {1000 * a.batch / ips:8.2f} ms/step"
