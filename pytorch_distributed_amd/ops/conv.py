@@ -61,6 +61,7 @@ _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7, 13)   # 13: 256x128 ring on 2
 # 33: the A-stationary pointwise kernel (csrc/kernels/pointwise_astat.hip): unpadded 1x1, 64 / 128 / 256 / 512 input
 # channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
 _FPROP_PW_CFG = 33
+_TUNE_LONG = os.environ.get("PDA_TUNE_LONG", "1") == "1"
 _FUSE_BIAS_RELU = os.environ.get("PDA_CONV_FUSE_BIAS_RELU", "1") == "1"   # plain convs: bias + ReLU in the GEMM epilogue
 _FPROP_C64_CFG = 34   # weight-stationary 3x3 on 64 -> 64 channels (csrc/kernels/conv3x3_c64.hip)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
@@ -87,13 +88,19 @@ def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
             times.append(float("inf"))
             continue
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            run(c)
-        e1.record()
-        torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1))
+        reps, t = 4, 0.0
+        while True:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run(c)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps
+            if reps >= 16 or t * reps >= 1.5 or not _TUNE_LONG:      # short kernels: a longer window, so that a few us of jitter do not decide
+                break
+            reps = 16
+        times.append(t)
     best = min(range(len(cands)), key=lambda i: times[i])
     choice = cands[best] if times[best] < 0.97 * times[0] else cands[0]
     _TUNED[k] = choice
