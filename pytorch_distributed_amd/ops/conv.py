@@ -62,6 +62,7 @@ _FPROP_CFGS = (0, 1, 2, 3, 9, 10, 11, 12, 5, 6, 7, 13)   # 13: 256x128 ring on 2
 # channels, 16-bit, plain or normalise-on-load input, statistics epilogue only
 _FPROP_PW_CFG = 33
 _TUNE_LONG = os.environ.get("PDA_TUNE_LONG", "1") == "1"
+_TUNE_MARGIN = float(os.environ.get("PDA_TUNE_MARGIN", "0.97"))   # a candidate replaces the heuristic below this ratio
 _FUSE_BIAS_RELU = os.environ.get("PDA_CONV_FUSE_BIAS_RELU", "1") == "1"   # plain convs: bias + ReLU in the GEMM epilogue
 _FPROP_C64_CFG = 34   # weight-stationary 3x3 on 64 -> 64 channels (csrc/kernels/conv3x3_c64.hip)
 _FPROP_XF_CFGS = (0, 1, 2, 3, 9, 10, 11, 12)  # input normalised on load: the register-staged tiles
@@ -102,7 +103,7 @@ def _tuned_cfg(kind: str, key: tuple, cands, run) -> int:
             reps = 16
         times.append(t)
     best = min(range(len(cands)), key=lambda i: times[i])
-    choice = cands[best] if times[best] < 0.97 * times[0] else cands[0]
+    choice = cands[best] if times[best] < _TUNE_MARGIN * times[0] else cands[0]
     _TUNED[k] = choice
     return choice
 
